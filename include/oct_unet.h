@@ -1,0 +1,129 @@
+/*
+ * oct_unet.h -- C ABI of the MI355X-native OCT U-Net engine (liboct_unet_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of
+ * NIH-NEI/oct-image-segmentation-models: the U-Net forward/backward + softmax/
+ * Dice head that the reference delegates to tf.keras (Model.fit / Model.predict).
+ * Plain C, plain pointers and sizes, no torch types.  Every device buffer is
+ * owned by the CALLER (any allocator: torch, hipMalloc); the handle owns only
+ * host-side plans.  No entry point allocates device memory, so every call after
+ * oct_unet_create() is hipGraph-capturable.  All launches are asynchronous on
+ * the caller-supplied stream.  One handle per GPU rank, driven by one host
+ * thread.
+ *
+ * Reference interface each entry point replaces (paths relative to
+ * /root/reference/oct_image_segmentation_models/):
+ *
+ *   oct_unet_create / _layer_info      UNet.__init__/build_model      models/unet.py:61-153
+ *   params/state buffer layout         Model.get_weights/set_weights  training.py:319-342 (checkpoint, early stop)
+ *   oct_unet_forward (training=0)      loaded_model.predict(...)      evaluation/evaluation.py:129-135,
+ *                                                                     prediction/prediction.py:75-81
+ *   oct_unet_forward (training=1)      Model.fit train step (fwd)     training/training.py:401-407
+ *     x_is_u8 preprocessing            get_preprocess_input_fn x/255  models/unet.py:87-91
+ *     io.argmax                        perform_argmax                 common/utils.py:80-112
+ *   oct_unet_loss_dice                 dice_loss_micro/_macro         common/custom_losses.py:47-81
+ *                                      dice_coef_micro/_macro         common/custom_metrics.py:18-77
+ *   oct_unet_backward                  Keras autodiff of the above    training/training.py:262-266,401-407
+ *   oct_adam_step / oct_sgd_step       optimizer.apply_gradients      training/training.py:190-193
+ *   gradient buffer (caller-owned)     MirroredStrategy all-reduce    training/training.py:185-188,243
+ *   oct_unet_graph_capture/_launch     (none: replaces per-call Keras dispatch overhead, evaluation.py:108-135)
+ */
+#ifndef OCT_UNET_H
+#define OCT_UNET_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oct_unet oct_unet;   /* opaque */
+typedef void* oct_stream_t;         /* a hipStream_t (NULL = default stream) */
+
+typedef struct oct_unet_cfg {
+    int in_ch;            /* input_channels                       (unet.py:65)          */
+    int n_cls;            /* num_classes, 2..8                    (training.py:176)     */
+    int H, W;             /* image_height, image_width; multiples of 2^pool_layers     */
+    int max_batch;        /* largest per-rank batch any call will pass                  */
+    int start_neurons;    /* default 8; multiple of 4             (unet.py:69)          */
+    int pool_layers;      /* default 4                            (unet.py:70)          */
+    int conv_layers;      /* default 2                            (unet.py:71)          */
+    int enc_k;            /* 3  (enc_kernel (3,3))                (unet.py:72)          */
+    int dec_k;            /* 2  (dec_kernel (2,2))                (unet.py:73)          */
+    int dtype;            /* 0 = f32 storage + f32 arithmetic (only mode implemented)   */
+    int training;         /* 1: workspace also holds saved activations + gradients      */
+    float bn_eps;         /* 1e-3  keras BatchNormalization default                     */
+    float bn_momentum;    /* 0.99                                                       */
+    float dropout_rate;   /* 0.5                                  (unet.py:130)         */
+    int bn_unbiased_moving_var; /* 1: moving_var fed with Bessel-corrected batch var (TF fused BN) */
+    unsigned long long seed;    /* dropout stream seed (differs per DP rank)            */
+} oct_unet_cfg;
+
+/* One Conv2D(+BN) node in Keras creation order; offsets are in floats. */
+typedef struct oct_layer_info {
+    char name[32];
+    int kh, kw, cin, cout, has_bn;
+    int out_h, out_w;
+    size_t kernel_off, bias_off, gamma_off, beta_off;     /* into params / grads buffers */
+    size_t moving_mean_off, moving_var_off;               /* into the state buffer        */
+} oct_layer_info;
+
+typedef struct oct_unet_io {
+    float* probs;                 /* (B,H,W,n_cls) f32 softmax output, or NULL           */
+    unsigned char* argmax;        /* (B,H,W) u8 class map, or NULL                       */
+    const unsigned char* labels;  /* (B,H,W) u8 sparse labels, or NULL; enables Dice sums */
+} oct_unet_io;
+
+/* ---- sizing (host only, no GPU needed) ---- */
+void   oct_unet_cfg_default(oct_unet_cfg* cfg);
+int    oct_unet_cfg_check(const oct_unet_cfg* cfg);              /* 0 ok, <0 + oct_last_error() */
+size_t oct_unet_param_count(const oct_unet_cfg* cfg);            /* trainable floats (487403 default, C=3) */
+size_t oct_unet_state_count(const oct_unet_cfg* cfg);            /* BN moving stats (1712 default)         */
+size_t oct_unet_workspace_bytes(const oct_unet_cfg* cfg);        /* activations, gradients, scratch        */
+int    oct_unet_layer_count(const oct_unet_cfg* cfg);
+int    oct_unet_layer_info(const oct_unet_cfg* cfg, int index, oct_layer_info* out);
+
+/* ---- lifetime ---- */
+/* params/grads: param_count floats; state: state_count floats; grads may be NULL when cfg.training==0. */
+int  oct_unet_create(const oct_unet_cfg* cfg, float* params_dev, float* grads_dev, float* state_dev,
+                     void* workspace_dev, size_t workspace_bytes, oct_unet** out);
+void oct_unet_destroy(oct_unet* h);
+
+/* ---- hot path ---- */
+/* x: (B,H,W,in_ch) u8 (x_is_u8: /255 table applied on load) or f32 already in [0,1].
+ * training=1: batch-statistic BN (+moving update), dropout, activations saved for backward. */
+int oct_unet_forward(oct_unet* h, const void* x_dev, int x_is_u8, int B, int training,
+                     const oct_unet_io* io, oct_stream_t stream);
+/* After a forward with io.labels: out4_dev = {dice_loss_macro, dice_loss_micro,
+ * dice_coef_macro, dice_coef_micro} (device floats). */
+int oct_unet_loss_dice(oct_unet* h, float smooth, float* out4_dev, oct_stream_t stream);
+/* After training forward + loss_dice: fills the grads buffer with d(loss_scale*loss)/dparams. */
+int oct_unet_backward(oct_unet* h, const unsigned char* labels_dev, int macro, float loss_scale,
+                      oct_stream_t stream);
+
+/* ---- optimizers on flat buffers (Keras formulations) ---- */
+int oct_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, size_t n,
+                  float lr, float beta1, float beta2, float eps, long step /*1-based*/, oct_stream_t stream);
+int oct_sgd_step(float* params_dev, const float* grads_dev, float* momentum_buf_dev /*or NULL*/, size_t n,
+                 float lr, float momentum, oct_stream_t stream);
+
+/* ---- dropout stream control (parity tests replay the mask) ---- */
+int oct_unet_set_dropout_step(oct_unet* h, unsigned long long step);
+/* keep-mask (B, H/2^P, W/2^P, start_neurons*2^P) u8 {0,1} that a training forward at the current step uses */
+int oct_unet_dropout_mask(oct_unet* h, int B, unsigned char* mask_dev, oct_stream_t stream);
+
+/* ---- inference hipGraph: capture one forward (training=0) with fixed buffers, then replay ---- */
+int oct_unet_graph_capture(oct_unet* h, const void* x_dev, int x_is_u8, int B, const oct_unet_io* io,
+                           oct_stream_t stream);
+int oct_unet_graph_launch(oct_unet* h, oct_stream_t stream);
+
+/* ---- introspection for tests: device pointer of a layer's saved pre-BN output / gradient ---- */
+const float* oct_unet_debug_activation(oct_unet* h, int layer, int which /*0=z,1=g*/);
+
+const char* oct_last_error(void);
+const char* oct_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCT_UNET_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of ``liboct_unet_hip.so`` (C ABI declared in ``include/oct_unet.h``).
+
+The library is built in-tree by ``csrc/build.sh`` (``__graft_entry__.build()``).
+Importing this module without the built library raises: the product path has
+no fallback implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboct_unet_hip.so")
+
+
+class OctError(RuntimeError):
+    pass
+
+
+class UNetCfg(C.Structure):
+    _fields_ = [
+        ("in_ch", C.c_int), ("n_cls", C.c_int), ("H", C.c_int), ("W", C.c_int), ("max_batch", C.c_int),
+        ("start_neurons", C.c_int), ("pool_layers", C.c_int), ("conv_layers", C.c_int),
+        ("enc_k", C.c_int), ("dec_k", C.c_int), ("dtype", C.c_int), ("training", C.c_int),
+        ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("dropout_rate", C.c_float),
+        ("bn_unbiased_moving_var", C.c_int), ("seed", C.c_ulonglong),
+    ]
+
+
+class LayerInfo(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 32),
+        ("kh", C.c_int), ("kw", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("has_bn", C.c_int),
+        ("out_h", C.c_int), ("out_w", C.c_int),
+        ("kernel_off", C.c_size_t), ("bias_off", C.c_size_t), ("gamma_off", C.c_size_t), ("beta_off", C.c_size_t),
+        ("moving_mean_off", C.c_size_t), ("moving_var_off", C.c_size_t),
+    ]
+
+
+class UNetIO(C.Structure):
+    _fields_ = [("probs", C.c_void_p), ("argmax", C.c_void_p), ("labels", C.c_void_p)]
+
+
+# every symbol include/oct_unet.h declares: (name, restype, argtypes)
+_P = C.POINTER
+SYMBOLS = [
+    ("oct_unet_cfg_default", None, [_P(UNetCfg)]),
+    ("oct_unet_cfg_check", C.c_int, [_P(UNetCfg)]),
+    ("oct_unet_param_count", C.c_size_t, [_P(UNetCfg)]),
+    ("oct_unet_state_count", C.c_size_t, [_P(UNetCfg)]),
+    ("oct_unet_workspace_bytes", C.c_size_t, [_P(UNetCfg)]),
+    ("oct_unet_layer_count", C.c_int, [_P(UNetCfg)]),
+    ("oct_unet_layer_info", C.c_int, [_P(UNetCfg), C.c_int, _P(LayerInfo)]),
+    ("oct_unet_create", C.c_int, [_P(UNetCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                  _P(C.c_void_p)]),
+    ("oct_unet_destroy", None, [C.c_void_p]),
+    ("oct_unet_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _P(UNetIO), C.c_void_p]),
+    ("oct_unet_loss_dice", C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    ("oct_unet_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    ("oct_adam_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
+                                C.c_float, C.c_float, C.c_long, C.c_void_p]),
+    ("oct_sgd_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p]),
+    ("oct_unet_set_dropout_step", C.c_int, [C.c_void_p, C.c_ulonglong]),
+    ("oct_unet_dropout_mask", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ("oct_unet_graph_capture", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(UNetIO), C.c_void_p]),
+    ("oct_unet_graph_launch", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("oct_unet_debug_activation", C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    ("oct_last_error", C.c_char_p, []),
+    ("oct_version", C.c_char_p, []),
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OctError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(csrc/build.sh).  There is no fallback implementation.")
+        l = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(l, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise OctError(f"{what} failed (rc={rc}): {lib().oct_last_error().decode()}")

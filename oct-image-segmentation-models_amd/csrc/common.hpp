@@ -1,0 +1,95 @@
+// Shared device helpers for the OCT U-Net HIP engine (gfx950 / CDNA4, wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oct {
+
+constexpr int kTileX = 32;   // pixel tile of the thread-per-pixel kernels: 32 (x, fastest across lanes) x 8 (y)
+constexpr int kTileY = 8;
+constexpr int kBlock = 256;  // 4 waves
+
+// per-layer BN device record: 6 arrays of C floats each, in this order
+enum { BN_A = 0, BN_B = 1, BN_MEAN = 2, BN_RSTD = 3, BN_C1 = 4, BN_C2 = 5, BN_ARRAYS = 6 };
+
+// input-fetch flags of the conv kernels
+enum { F_U8 = 1, F_AFF = 2, F_TWO = 4, F_UP = 8, F_DROP = 16 };
+
+__constant__ float c_u8_lut[256];  // float32(i / 255.0): bit-identical to the reference's x/255.0 path
+
+// Counter-based dropout stream: keep(element) = hash(seed, step, idx) >= thresh.  Regenerated in
+// forward, dX and dW, so no mask tensor is ever stored.
+__host__ __device__ inline uint32_t drop_hash(uint64_t seed, uint64_t step, uint32_t idx) {
+    uint64_t x = seed ^ (step * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)idx * 0xD1B54A32D192ED03ull);
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return (uint32_t)(x >> 32);
+}
+
+struct DropCfg {
+    unsigned long long seed, step;
+    unsigned thresh;   // keep iff hash >= thresh  (rate * 2^32)
+    float scale;       // 1 / (1 - rate)
+};
+
+__device__ inline float drop_mul(const DropCfg& d, uint32_t idx) {
+    return drop_hash(d.seed, d.step, idx) >= d.thresh ? d.scale : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wavefront-level multi-value reduction (64 lanes, N values per lane, N a power of two <= 64).
+// Halving butterfly: at each step a lane keeps half of its values and hands the other half to its
+// partner, so N values cost N-1 (+ log2(64/N)) shuffles instead of 6N.  On return v[0] of EVERY
+// lane holds the wave total of channel chan_of_lane<N>(lane); lane c*(64/N) is a holder of channel c.
+// ------------------------------------------------------------------------------------------------
+template <int NFULL, int N, int OFF>
+__device__ inline void wave_reduce_rec(float (&v)[NFULL], int lane) {
+    if constexpr (N > 1) {
+        const bool upper = (lane & OFF) != 0;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const float send = upper ? v[i] : v[i + N / 2];
+            const float keep = upper ? v[i + N / 2] : v[i];
+            v[i] = keep + __shfl_xor(send, OFF, 64);
+        }
+        wave_reduce_rec<NFULL, N / 2, OFF / 2>(v, lane);
+    } else if constexpr (OFF >= 1) {
+        v[0] += __shfl_xor(v[0], OFF, 64);
+        wave_reduce_rec<NFULL, 1, OFF / 2>(v, lane);
+    }
+}
+
+template <int N>
+__device__ inline void wave_reduce_multi(float (&v)[N]) {
+    static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "N must be a power of two <= 64");
+    wave_reduce_rec<N, N, 32>(v, threadIdx.x & 63);
+}
+
+// Block (4 waves) reduction of N per-thread values -> out[0..N) written by threads 0..N-1.
+// `red` is 4*64 floats of LDS.  Contains two __syncthreads(); every thread of the block must call it.
+template <int N>
+__device__ inline void block_reduce_store(float (&v)[N], float* red, float* out, int nvalid) {
+    wave_reduce_multi<N>(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    red[wave * 64 + lane] = v[0];
+    __syncthreads();
+    if ((int)threadIdx.x < N && (int)threadIdx.x < nvalid) {
+        const int l = threadIdx.x * (64 / N);
+        out[threadIdx.x] = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+    }
+    __syncthreads();
+}
+
+// which of the N channels lane `lane` holds after wave_reduce_multi<N> (used by tests of the helper)
+template <int N>
+__host__ __device__ inline int chan_of_lane(int lane) {
+    int c = 0, n = N, off = 32;
+    while (n > 1) { if (lane & off) c += n / 2; n >>= 1; off >>= 1; }
+    return c;
+}
+
+__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
+}  // namespace oct

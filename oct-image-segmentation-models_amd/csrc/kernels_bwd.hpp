@@ -1,0 +1,412 @@
+// Backward kernels.
+//
+// Gradient flow contract: for a conv block  z = conv(x)+bias, y = relu(BN(z)):
+//   * whoever produces dL/dy writes g' = dL/dy * [y>0] (* dropout) into the block's g buffer and emits
+//     per-block partials of  sum(g')  and  sum(g' * xhat)  (the two BN-backward reductions = dbeta, dgamma);
+//   * bn_bwd_finalize turns the partials into c1 = sum(g')/N, c2 = sum(g' xhat)/N and dgamma/dbeta;
+//   * bn_bwd_apply rewrites g' in place into dz = gamma*rstd*(g' - c1 - xhat*c2);
+//   * conv_bwd_w reduces dW = sum x (x) dz, conv_bwd_data scatters dz back to the block's input(s).
+#pragma once
+#include "common.hpp"
+#include "kernels_fwd.hpp"
+
+namespace oct {
+
+// ---- epilogue shared by every producer of a BN block's output gradient -----------------------------------
+// g[CI_T] = dL/dy at one pixel for channels [c0, c0+CI_T) -> masked by the block's ReLU, statistics emitted.
+template <int CI_T, bool DROP>
+__device__ inline void mask_and_stats(float (&g)[CI_T], bool valid, const float* __restrict__ zin_px,
+                                      const float* __restrict__ bn, int C, int c0, uint32_t elem0,
+                                      const DropCfg& drop, float* red, float* part_out) {
+    float s1[CI_T], s2[CI_T];
+#pragma unroll
+    for (int i = 0; i < CI_T; i += 4) {
+        const float4 zv = valid ? ld4(zin_px + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + i + k;
+            const float yv = fmaf(bn[BN_A * C + c], zz[k], bn[BN_B * C + c]);
+            float gv = g[i + k];
+            if constexpr (DROP) gv *= drop_mul(drop, elem0 + i + k);
+            gv = (valid && yv > 0.f) ? gv : 0.f;
+            const float xh = (zz[k] - bn[BN_MEAN * C + c]) * bn[BN_RSTD * C + c];
+            g[i + k] = gv; s1[i + k] = gv; s2[i + k] = gv * xh;
+        }
+    }
+    block_reduce_store<CI_T>(s1, red, part_out + c0, CI_T);
+    block_reduce_store<CI_T>(s2, red, part_out + C + c0, CI_T);
+}
+
+// ---- conv backward-data -------------------------------------------------------------------------------------
+struct ConvBwdDataArgs {
+    const float* dz;  // (B,H,W,Cout)
+    const float* w;   // (KH,KW,Cin_total,Cout)
+    int Cin_total, Cout, ci_off;
+    float* g;         // (B,Hg,Wg,Cg) gradient wrt this group of input channels
+    int Cg;
+    int H, W;         // dz dims
+    int Hg, Wg, tiles_x, tiles;
+    const float* zin; // producer's raw output (B,Hg,Wg,Cg)   [EPI]
+    const float* bnin;
+    float* part;      // [B*tiles][2*Cg]
+    int accumulate;   // RAW epilogue: g += (second writer of a skip gradient)
+    DropCfg drop;
+};
+
+enum { E_RAW = 0, E_MASK = 1, E_MASK_DROP = 2 };
+
+// One thread = one pixel of the INPUT tensor x CI_T input channels.  grid (tiles, Cg/CI_T, B).
+// UP: the conv consumed a nearest-upsampled tensor, so the 2x2 window sum (UpSampling2D grad) is fused here.
+template <int KH, int CI_T, bool UP, int EPI>
+__global__ __launch_bounds__(kBlock) void conv_bwd_data_k(const ConvBwdDataArgs A) {
+    constexpr int KW = KH, PT = (KH - 1) / 2;
+    __shared__ float red[256];
+    const int tx = threadIdx.x & (kTileX - 1), ty = threadIdx.x / kTileX;
+    const int tile = blockIdx.x;
+    const int x = (tile % A.tiles_x) * kTileX + tx, y = (tile / A.tiles_x) * kTileY + ty;
+    const int b = blockIdx.z, c0 = blockIdx.y * CI_T;
+    const bool valid = x < A.Wg && y < A.Hg;
+    float acc[CI_T];
+#pragma unroll
+    for (int i = 0; i < CI_T; ++i) acc[i] = 0.f;
+
+    constexpr int NS = UP ? 2 : 1;
+    for (int dy = 0; dy < NS; ++dy)
+        for (int dx = 0; dx < NS; ++dx) {
+            const int Y = UP ? 2 * y + dy : y, X = UP ? 2 * x + dx : x;
+            for (int ky = 0; ky < KH; ++ky)
+                for (int kx = 0; kx < KW; ++kx) {
+                    const int oy = Y - ky + PT, ox = X - kx + PT;
+                    const bool inb = valid && oy >= 0 && oy < A.H && ox >= 0 && ox < A.W;
+                    const float* dp = A.dz + (inb ? (((size_t)b * A.H + oy) * A.W + ox) * A.Cout : 0);
+                    const float* wk = A.w + ((size_t)(ky * KW + kx) * A.Cin_total + A.ci_off + c0) * A.Cout;
+                    for (int co = 0; co < A.Cout; co += 4) {
+                        const float4 d = inb ? ld4(dp + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int i = 0; i < CI_T; ++i) {
+                            const float* wr = wk + (size_t)i * A.Cout + co;
+                            acc[i] = fmaf(d.x, wr[0], fmaf(d.y, wr[1], fmaf(d.z, wr[2], fmaf(d.w, wr[3], acc[i]))));
+                        }
+                    }
+                }
+        }
+    const size_t pix = valid ? ((size_t)b * A.Hg + y) * A.Wg + x : 0;
+    if constexpr (EPI != E_RAW) {
+        mask_and_stats<CI_T, EPI == E_MASK_DROP>(acc, valid, A.zin + pix * A.Cg + c0, A.bnin, A.Cg, c0,
+                                                 (uint32_t)(pix * A.Cg + c0), A.drop, red,
+                                                 A.part + ((size_t)b * A.tiles + tile) * (2 * A.Cg));
+    }
+    if (valid) {
+        float* gp = A.g + pix * A.Cg + c0;
+#pragma unroll
+        for (int i = 0; i < CI_T; i += 4) {
+            float4 o = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
+            if (EPI == E_RAW && A.accumulate) { const float4 p = ld4(gp + i); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+            st4(gp + i, o);
+        }
+    }
+}
+
+// ---- max-pool backward + skip-gradient merge + ReLU mask + BN-backward statistics ---------------------------
+// The encoder block's output y feeds (i) the pool and (ii) the decoder concat.  gskip already holds the
+// decoder's raw contribution; this kernel adds the pool's routed gradient, masks and emits the statistics.
+struct PoolBwdArgs {
+    const float* gp;   // (B,H/2,W/2,C) gradient wrt pooled tensor
+    const float* z;    // (B,H,W,C) block's raw output
+    const float* bn;
+    float* g;          // (B,H,W,C): in = decoder contribution (raw), out = masked total
+    float* part;       // [B*tiles][2*C]   tiles over the POOLED grid
+    int H, W, C, tiles_x, tiles;
+};
+
+template <int C_T>
+__global__ __launch_bounds__(kBlock) void pool_bwd_k(const PoolBwdArgs A) {
+    __shared__ float red[256];
+    const int Ho = A.H >> 1, Wo = A.W >> 1;
+    const int tx = threadIdx.x & (kTileX - 1), ty = threadIdx.x / kTileX;
+    const int tile = blockIdx.x;
+    const int xo = (tile % A.tiles_x) * kTileX + tx, yo = (tile / A.tiles_x) * kTileY + ty;
+    const int b = blockIdx.z, c0 = blockIdx.y * C_T;
+    const bool valid = xo < Wo && yo < Ho;
+    float s1[C_T], s2[C_T];
+#pragma unroll
+    for (int i = 0; i < C_T; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    if (valid) {
+        float gpv[C_T], zv[4][C_T], yv[4][C_T];
+        const float* gpp = A.gp + (((size_t)b * Ho + yo) * Wo + xo) * A.C + c0;
+#pragma unroll
+        for (int i = 0; i < C_T; i += 4) { const float4 t = ld4(gpp + i); gpv[i] = t.x; gpv[i + 1] = t.y; gpv[i + 2] = t.z; gpv[i + 3] = t.w; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* zp = A.z + (((size_t)b * A.H + 2 * yo + (q >> 1)) * A.W + 2 * xo + (q & 1)) * A.C + c0;
+#pragma unroll
+            for (int i = 0; i < C_T; i += 4) { const float4 t = ld4(zp + i); zv[q][i] = t.x; zv[q][i + 1] = t.y; zv[q][i + 2] = t.z; zv[q][i + 3] = t.w; }
+        }
+#pragma unroll
+        for (int i = 0; i < C_T; ++i) {
+            const int c = c0 + i;
+            const float a = A.bn[BN_A * A.C + c], bb = A.bn[BN_B * A.C + c];
+            int am = 0; float best = -1.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                yv[q][i] = fmaxf(fmaf(a, zv[q][i], bb), 0.f);
+                if (yv[q][i] > best) { best = yv[q][i]; am = q; }   // first maximum in row-major window order
+            }
+            // overwrite zv with the routed pool gradient so the store loop below stays branch-free
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zv[q][i] = (q == am ? gpv[i] : 0.f);
+            // keep raw z for xhat in yv's sign: recompute xhat from a: xhat = (z-mean)*rstd, need z again
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t off = (((size_t)b * A.H + 2 * yo + (q >> 1)) * A.W + 2 * xo + (q & 1)) * A.C + c0;
+            float* gq = A.g + off;
+            const float* zp = A.z + off;
+#pragma unroll
+            for (int i = 0; i < C_T; i += 4) {
+                const float4 gd = ld4(gq + i);
+                const float4 zz = ld4(zp + i);
+                const float gdv[4] = {gd.x, gd.y, gd.z, gd.w}, zzv[4] = {zz.x, zz.y, zz.z, zz.w};
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c0 + i + k;
+                    const float gt = yv[q][i + k] > 0.f ? gdv[k] + zv[q][i + k] : 0.f;
+                    const float xh = (zzv[k] - A.bn[BN_MEAN * A.C + c]) * A.bn[BN_RSTD * A.C + c];
+                    o[k] = gt; s1[i + k] += gt; s2[i + k] += gt * xh;
+                }
+                st4(gq + i, make_float4(o[0], o[1], o[2], o[3]));
+            }
+        }
+    }
+    float* out = A.part + ((size_t)b * A.tiles + tile) * (2 * A.C);
+    block_reduce_store<C_T>(s1, red, out + c0, C_T);
+    block_reduce_store<C_T>(s2, red, out + A.C + c0, C_T);
+}
+
+// ---- BN backward finalize + apply -------------------------------------------------------------------------------
+struct BnBwdFinArgs {
+    const float* part; int nblk, C; double count;
+    float* bn; float* dgamma; float* dbeta;
+};
+
+__global__ __launch_bounds__(kBlock) void bn_bwd_finalize_k(const BnBwdFinArgs A) {
+    __shared__ double sh[2][kBlock];
+    const int c = blockIdx.x;
+    double s = 0, q = 0;
+    for (int i = threadIdx.x; i < A.nblk; i += kBlock) {
+        s += A.part[(size_t)i * 2 * A.C + c];
+        q += A.part[(size_t)i * 2 * A.C + A.C + c];
+    }
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        A.dbeta[c] = (float)sh[0][0];
+        A.dgamma[c] = (float)sh[1][0];
+        A.bn[BN_C1 * A.C + c] = (float)(sh[0][0] / A.count);
+        A.bn[BN_C2 * A.C + c] = (float)(sh[1][0] / A.count);
+    }
+}
+
+// dz = gamma*rstd*(g' - c1 - xhat*c2), in place over g'
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_k(float* __restrict__ g, const float* __restrict__ z,
+                                                        const float* __restrict__ bn, const float* __restrict__ gamma,
+                                                        size_t n4, int C) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
+        const int c = (int)((i * 4) % C);
+        const float4 gv = ld4(g + i * 4), zv = ld4(z + i * 4);
+        const float4 mean = ld4(bn + BN_MEAN * C + c), rstd = ld4(bn + BN_RSTD * C + c);
+        const float4 c1 = ld4(bn + BN_C1 * C + c), c2 = ld4(bn + BN_C2 * C + c), gm = ld4(gamma + c);
+        float4 o;
+        o.x = gm.x * rstd.x * (gv.x - c1.x - (zv.x - mean.x) * rstd.x * c2.x);
+        o.y = gm.y * rstd.y * (gv.y - c1.y - (zv.y - mean.y) * rstd.y * c2.y);
+        o.z = gm.z * rstd.z * (gv.z - c1.z - (zv.z - mean.z) * rstd.z * c2.z);
+        o.w = gm.w * rstd.w * (gv.w - c1.w - (zv.w - mean.w) * rstd.w * c2.w);
+        st4(g + i * 4, o);
+    }
+}
+
+// ---- head backward: Dice gradient -> softmax Jacobian -> 1x1 conv backward-data -> mask + stats ----------------
+struct HeadBwdArgs {
+    const float* z; const float* bn;     // last conv block
+    const float* w; const float* bias;   // head (CIN,C),(C)
+    const unsigned char* labels;
+    const double* bc;                    // Dice constants from dice_finalize_k
+    float* dlogits;                      // (B,H,W,C)
+    float* g;                            // (B,H,W,CIN) masked gradient of the last conv block
+    float* part;                         // [B*nblk][2*CIN]
+    int HW, nblk, B, macro; float loss_scale;
+};
+
+template <int C, int CIN>
+__global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
+    __shared__ float red[256];
+    const int b = blockIdx.y;
+    const int px = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = px < A.HW;
+    const size_t pix = (size_t)b * A.HW + (valid ? px : 0);
+    float y[CIN], zr[CIN], p[C];
+    head_logits<C, CIN>(A.z + pix * CIN, A.bn, A.w, A.bias, y, zr, p);
+    const int lab = A.labels[pix];
+    float dp[C], dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const double* k = A.macro ? A.bc + 2 * (b * C + c) : A.bc + 2 * A.B * C;
+        const float num = (float)k[0], den = (float)k[1];
+        const float yv = lab == c ? 1.f : 0.f;
+        const float scale = A.macro ? A.loss_scale / (float)(A.B * C) : A.loss_scale;
+        dp[c] = -scale * (2.f * yv * den - num) / (den * den);
+        dot = fmaf(p[c], dp[c], dot);
+    }
+    float dl[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dl[c] = valid ? p[c] * (dp[c] - dot) : 0.f;
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) A.dlogits[pix * C + c] = dl[c];
+    }
+    float g[CIN], s1[CIN], s2[CIN];
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) a = fmaf(A.w[i * C + c], dl[c], a);
+        a = (valid && y[i] > 0.f) ? a : 0.f;
+        const float xh = (zr[i] - A.bn[BN_MEAN * CIN + i]) * A.bn[BN_RSTD * CIN + i];
+        g[i] = a; s1[i] = a; s2[i] = a * xh;
+    }
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < CIN; i += 4) st4(A.g + pix * CIN + i, make_float4(g[i], g[i + 1], g[i + 2], g[i + 3]));
+    }
+    float* out = A.part + ((size_t)b * A.nblk + blockIdx.x) * (2 * CIN);
+    block_reduce_store<CIN>(s1, red, out, CIN);
+    block_reduce_store<CIN>(s2, red, out + CIN, CIN);
+}
+
+// ---- conv backward-weights (LDS-staged tiles, per-block partial dW, deterministic second-stage sum) ------------
+struct ConvBwdWArgs {
+    const void* x0; const float* ab0; int C0;   // conv input, same fetch semantics as the forward kernel
+    const float* x1; const float* ab1; int C1;
+    int flags;                                  // F_* (runtime here: staging is outside the FMA loop)
+    const float* dz;                            // (B,H,W,Cout)
+    float* part;                                // [npb][KH*KW*Cin*Cout + Cout]
+    int B, H, W, Cin, Cout, tiles_x, tiles, total_tiles, npb;
+    DropCfg drop;
+};
+
+__device__ __forceinline__ float fetch_x(const ConvBwdWArgs& A, int b, int iy, int ix, int c) {
+    // activated conv input at (b, iy, ix, channel c of the concatenated input); caller guarantees in-bounds
+    const bool up = (A.flags & F_UP) != 0;
+    const int Hs = up ? A.H >> 1 : A.H, Ws = up ? A.W >> 1 : A.W;
+    const int sy = up ? iy >> 1 : iy, sx = up ? ix >> 1 : ix;
+    const size_t pix = ((size_t)b * Hs + sy) * Ws + sx;
+    if (A.flags & F_U8) return c_u8_lut[reinterpret_cast<const unsigned char*>(A.x0)[pix * A.C0 + c]];
+    const float* src = reinterpret_cast<const float*>(A.x0); const float* ab = A.ab0; int C = A.C0, cc = c;
+    if ((A.flags & F_TWO) && c >= A.C0) { src = A.x1; ab = A.ab1; C = A.C1; cc = c - A.C0; }
+    float v = src[pix * C + cc];
+    if (A.flags & F_AFF) v = fmaxf(fmaf(ab[cc], v, ab[C + cc]), 0.f);
+    if (A.flags & F_DROP) v *= drop_mul(A.drop, (uint32_t)(pix * C + cc));
+    return v;
+}
+
+// grid (npb, Cin/CI_T, ceil(Cout/CO_T)); thread t: entry e = t % (CI_T*CO_T) -> (ci, co); pixel split t / (CI_T*CO_T)
+template <int KH, int CI_T, int CO_T>
+__global__ __launch_bounds__(kBlock) void conv_bwd_w_k(const ConvBwdWArgs A) {
+    constexpr int KW = KH, PT = (KH - 1) / 2, NT = CI_T * CO_T, PS = kBlock / NT, TAPS = KH * KW;
+    constexpr int XH = kTileY + KH - 1, XW = kTileX + KW - 1;
+    static_assert(NT <= kBlock && kBlock % NT == 0, "entry tile must divide the block");
+    __shared__ float Xs[XH * XW * CI_T];
+    __shared__ float Ds[kTileY * kTileX * CO_T];
+    __shared__ float Rs[kBlock * (TAPS + 1)];
+    const int t = threadIdx.x, e = t % NT, ps = t / NT, ci = e / CO_T, co = e % CO_T;
+    const int ci0 = blockIdx.y * CI_T, co0 = blockIdx.z * CO_T;
+    float acc[TAPS], accb = 0.f;
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) acc[k] = 0.f;
+
+    for (int tl = blockIdx.x; tl < A.total_tiles; tl += A.npb) {
+        const int b = tl / A.tiles, tile = tl % A.tiles;
+        const int x0 = (tile % A.tiles_x) * kTileX, y0 = (tile / A.tiles_x) * kTileY;
+        __syncthreads();
+        for (int i = t; i < XH * XW * CI_T; i += kBlock) {
+            const int c = i % CI_T, r = i / CI_T, cx = r % XW, cy = r / XW;
+            const int iy = y0 + cy - PT, ix = x0 + cx - PT;
+            float v = 0.f;
+            if (iy >= 0 && iy < A.H && ix >= 0 && ix < A.W && ci0 + c < A.Cin) v = fetch_x(A, b, iy, ix, ci0 + c);
+            Xs[i] = v;
+        }
+        for (int i = t; i < kTileY * kTileX * CO_T; i += kBlock) {
+            const int c = i % CO_T, r = i / CO_T, cx = r % kTileX, cy = r / kTileX;
+            const int oy = y0 + cy, ox = x0 + cx;
+            float v = 0.f;
+            if (oy < A.H && ox < A.W && co0 + c < A.Cout) v = A.dz[(((size_t)b * A.H + oy) * A.W + ox) * A.Cout + co0 + c];
+            Ds[i] = v;
+        }
+        __syncthreads();
+        for (int p = ps; p < kTileY * kTileX; p += PS) {
+            const int py = p / kTileX, pxx = p % kTileX;
+            const float d = Ds[p * CO_T + co];
+            accb += d;
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+                    acc[ky * KW + kx] = fmaf(Xs[((py + ky) * XW + pxx + kx) * CI_T + ci], d, acc[ky * KW + kx]);
+        }
+    }
+    // reduce the PS pixel-split groups
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) Rs[t * (TAPS + 1) + k] = acc[k];
+    Rs[t * (TAPS + 1) + TAPS] = accb;
+    __syncthreads();
+    if (t < NT) {
+        const size_t wsize = (size_t)TAPS * A.Cin * A.Cout;
+        float* out = A.part + (size_t)blockIdx.x * (wsize + A.Cout);
+        const bool ok = (ci0 + ci < A.Cin) && (co0 + co < A.Cout);
+        for (int k = 0; k <= TAPS; ++k) {
+            float s = 0.f;
+            for (int q = 0; q < PS; ++q) s += Rs[(q * NT + t) * (TAPS + 1) + k];
+            if (!ok) continue;
+            if (k < TAPS) out[((size_t)k * A.Cin + ci0 + ci) * A.Cout + co0 + co] = s;
+            else if (ci0 + ci == 0) out[wsize + co0 + co] = s;   // bias gradient = sum dz
+        }
+    }
+}
+
+// second stage: grads[j] = sum over pixel blocks of part[pb][j]
+__global__ __launch_bounds__(kBlock) void reduce_partials_k(const float* __restrict__ part, int npb, size_t stride,
+                                                           size_t wsize, float* __restrict__ dw, float* __restrict__ db) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= stride) return;
+    double s = 0;
+    for (int p = 0; p < npb; ++p) s += part[(size_t)p * stride + j];
+    if (j < wsize) dw[j] = (float)s; else db[j - wsize] = (float)s;
+}
+
+// ---- optimizers (Keras formulations) ----------------------------------------------------
+__global__ __launch_bounds__(kBlock) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sgd_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
+                                               size_t n, float lr, float momentum) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        if (mom) { const float vi = momentum * mom[i] - lr * g[i]; mom[i] = vi; p[i] += vi; }
+        else p[i] -= lr * g[i];
+    }
+}
+
+}  // namespace oct

@@ -1,0 +1,329 @@
+// Forward kernels: conv (+bias, +BN-stat partials, input transform fused on load), BN finalize,
+// max-pool (BN+ReLU fused on load), 1x1 head + softmax + Dice partial sums (+argmax).
+//
+// Fusion contract: a conv WRITES its raw output z (pre-BN); BatchNorm+ReLU (+dropout,
+// +nearest-upsample, +concat) are applied by the CONSUMER when it loads z, using the per-channel
+// affine (a, b) that bn_fwd_finalize derives from the conv's own per-block (sum, sum^2) partials.
+#pragma once
+#include "common.hpp"
+
+namespace oct {
+
+struct ConvFwdArgs {
+    const void* x0;    // source 0: u8 or f32 (B,Hs,Ws,C0)
+    const float* ab0;  // BN record of source 0 (a at +0, b at +C0) when F_AFF
+    int C0;
+    const float* x1;   // source 1 (concat skip half) when F_TWO
+    const float* ab1;
+    int C1;
+    const float* w;    // (KH,KW,Cin,Cout) HWIO
+    const float* bias; // (Cout)
+    float* z;          // (B,H,W,Cout)
+    float* part;       // [B*tiles][2*Cout] stat partials or nullptr
+    int H, W, Cin, Cout, tiles_x, tiles;
+    DropCfg drop;
+};
+
+// acc[j] += sum_c f(src[pix][c]) * w[c][j]   (w row stride = Cout; all weight addresses wave-uniform)
+template <int CO_T, int FLAGS>
+__device__ inline void accum_src(const void* __restrict__ src, const float* __restrict__ ab, int C, size_t pix,
+                                 bool inb, const float* __restrict__ wk, int Cout, const DropCfg& drop,
+                                 float (&acc)[CO_T]) {
+    constexpr bool U8 = (FLAGS & F_U8) != 0, AFF = (FLAGS & F_AFF) != 0, DROP = (FLAGS & F_DROP) != 0;
+    if constexpr (!U8) {
+        if ((C & 3) == 0) {
+            const float* p = reinterpret_cast<const float*>(src) + pix * C;
+            for (int c = 0; c < C; c += 4) {
+                float4 v = inb ? ld4(p + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (AFF) {
+                    const float4 a = ld4(ab + c), b = ld4(ab + C + c);
+                    v.x = inb ? fmaxf(fmaf(a.x, v.x, b.x), 0.f) : 0.f;
+                    v.y = inb ? fmaxf(fmaf(a.y, v.y, b.y), 0.f) : 0.f;
+                    v.z = inb ? fmaxf(fmaf(a.z, v.z, b.z), 0.f) : 0.f;
+                    v.w = inb ? fmaxf(fmaf(a.w, v.w, b.w), 0.f) : 0.f;
+                }
+                if constexpr (DROP) {
+                    const uint32_t e = (uint32_t)(pix * C + c);
+                    v.x *= drop_mul(drop, e); v.y *= drop_mul(drop, e + 1);
+                    v.z *= drop_mul(drop, e + 2); v.w *= drop_mul(drop, e + 3);
+                }
+                const float* wr = wk + (size_t)c * Cout;
+#pragma unroll
+                for (int j = 0; j < CO_T; ++j) acc[j] = fmaf(v.x, wr[j], acc[j]);
+#pragma unroll
+                for (int j = 0; j < CO_T; ++j) acc[j] = fmaf(v.y, wr[Cout + j], acc[j]);
+#pragma unroll
+                for (int j = 0; j < CO_T; ++j) acc[j] = fmaf(v.z, wr[2 * Cout + j], acc[j]);
+#pragma unroll
+                for (int j = 0; j < CO_T; ++j) acc[j] = fmaf(v.w, wr[3 * Cout + j], acc[j]);
+            }
+            return;
+        }
+    }
+    // scalar channel loop: u8 input or a channel count that is not a multiple of 4 (first layer)
+    for (int c = 0; c < C; ++c) {
+        float v = 0.f;
+        if (inb) {
+            if constexpr (U8) v = c_u8_lut[reinterpret_cast<const unsigned char*>(src)[pix * C + c]];
+            else v = reinterpret_cast<const float*>(src)[pix * C + c];
+            if constexpr (AFF) v = fmaxf(fmaf(ab[c], v, ab[C + c]), 0.f);
+        }
+        const float* wr = wk + (size_t)c * Cout;
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+    }
+}
+
+// One thread = one output pixel x CO_T output channels.  grid (tiles, Cout/CO_T, B), block 256.
+template <int KH, int CO_T, int FLAGS>
+__global__ __launch_bounds__(kBlock) void conv_fwd_k(const ConvFwdArgs A) {
+    constexpr int KW = KH, PT = (KH - 1) / 2;
+    constexpr bool TWO = (FLAGS & F_TWO) != 0, UP = (FLAGS & F_UP) != 0;
+    __shared__ float red[256];
+    const int tx = threadIdx.x & (kTileX - 1), ty = threadIdx.x / kTileX;
+    const int tile = blockIdx.x;
+    const int x = (tile % A.tiles_x) * kTileX + tx, y = (tile / A.tiles_x) * kTileY + ty;
+    const int b = blockIdx.z, co0 = blockIdx.y * CO_T;
+    const bool valid = x < A.W && y < A.H;
+    const int Hs = UP ? A.H >> 1 : A.H, Ws = UP ? A.W >> 1 : A.W;
+
+    float acc[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) acc[j] = A.bias[co0 + j];
+
+    for (int ky = 0; ky < KH; ++ky) {
+        for (int kx = 0; kx < KW; ++kx) {
+            const int iy = y + ky - PT, ix = x + kx - PT;
+            const bool inb = valid && iy >= 0 && iy < A.H && ix >= 0 && ix < A.W;
+            const int sy = UP ? iy >> 1 : iy, sx = UP ? ix >> 1 : ix;
+            const size_t pix = inb ? ((size_t)b * Hs + sy) * Ws + sx : 0;
+            const float* wk = A.w + (size_t)((ky * KW + kx) * A.Cin) * A.Cout + co0;
+            accum_src<CO_T, FLAGS>(A.x0, A.ab0, A.C0, pix, inb, wk, A.Cout, A.drop, acc);
+            if constexpr (TWO)
+                accum_src<CO_T, FLAGS>(A.x1, A.ab1, A.C1, pix, inb, wk + (size_t)A.C0 * A.Cout, A.Cout, A.drop, acc);
+        }
+    }
+    if (valid) {
+        float* zp = A.z + (((size_t)b * A.H + y) * A.W + x) * A.Cout + co0;
+#pragma unroll
+        for (int j = 0; j < CO_T; j += 4) st4(zp + j, make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]));
+    }
+    if (A.part) {  // per-block BatchNorm statistics of this conv's own output
+        float s[CO_T], q[CO_T];
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j) { s[j] = valid ? acc[j] : 0.f; q[j] = s[j] * s[j]; }
+        float* out = A.part + ((size_t)b * A.tiles + tile) * (2 * A.Cout);
+        block_reduce_store<CO_T>(s, red, out + co0, CO_T);
+        block_reduce_store<CO_T>(q, red, out + A.Cout + co0, CO_T);
+    }
+}
+
+// ---- BN finalize (training): partials -> mean / biased var -> (a, b); moving-stat update -----------------
+struct BnFinArgs {
+    const float* part;  // [nblk][2*C]
+    int nblk, C;
+    double count;       // B*H*W
+    const float* gamma; const float* beta;
+    float* bn;          // record (BN_ARRAYS * C)
+    float* mm; float* mv;
+    float eps, momentum; int unbiased;
+};
+
+__global__ __launch_bounds__(kBlock) void bn_fwd_finalize_k(const BnFinArgs A) {
+    __shared__ double sh[2][kBlock];
+    const int c = blockIdx.x;
+    double s = 0, q = 0;
+    for (int i = threadIdx.x; i < A.nblk; i += kBlock) {
+        s += A.part[(size_t)i * 2 * A.C + c];
+        q += A.part[(size_t)i * 2 * A.C + A.C + c];
+    }
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = sh[0][0] / A.count;
+        double var = sh[1][0] / A.count - mean * mean;
+        if (var < 0) var = 0;
+        const double rstd = 1.0 / sqrt(var + (double)A.eps);
+        const double a = (double)A.gamma[c] * rstd;
+        A.bn[BN_A * A.C + c] = (float)a;
+        A.bn[BN_B * A.C + c] = (float)((double)A.beta[c] - mean * a);
+        A.bn[BN_MEAN * A.C + c] = (float)mean;
+        A.bn[BN_RSTD * A.C + c] = (float)rstd;
+        const double m = A.momentum;
+        const double uv = (A.unbiased && A.count > 1) ? var * (A.count / (A.count - 1.0)) : var;
+        A.mm[c] = (float)((double)A.mm[c] * m + mean * (1.0 - m));
+        A.mv[c] = (float)((double)A.mv[c] * m + uv * (1.0 - m));
+    }
+}
+
+// inference: (a, b) from the moving statistics, one thread per channel of one layer
+__global__ void bn_infer_coeffs_k(const float* gamma, const float* beta, const float* mm, const float* mv,
+                                  float* bn, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float a = gamma[c] / sqrtf(mv[c] + eps);
+    bn[BN_A * C + c] = a;
+    bn[BN_B * C + c] = beta[c] - mm[c] * a;
+    bn[BN_MEAN * C + c] = mm[c];
+    bn[BN_RSTD * C + c] = 1.f / sqrtf(mv[c] + eps);
+}
+
+// ---- max-pool 2x2 with BN+ReLU fused on load: p = max over window of relu(a*z+b) -------------------------
+__global__ __launch_bounds__(kBlock) void pool_fwd_k(const float* __restrict__ z, const float* __restrict__ ab,
+                                                    float* __restrict__ p, int B, int H, int W, int C) {
+    // H, W: INPUT dims.  one thread = one pooled pixel x 4 channels
+    const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    const size_t n = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const int c = (int)(i % C4) * 4;
+        size_t r = i / C4;
+        const int xo = (int)(r % Wo); r /= Wo;
+        const int yo = (int)(r % Ho); const int b = (int)(r / Ho);
+        const float4 a = ld4(ab + c), bb = ld4(ab + C + c);
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // relu output >= 0
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const float4 v = ld4(z + (((size_t)b * H + 2 * yo + dy) * W + 2 * xo + dx) * C + c);
+                m.x = fmaxf(m.x, fmaf(a.x, v.x, bb.x)); m.y = fmaxf(m.y, fmaf(a.y, v.y, bb.y));
+                m.z = fmaxf(m.z, fmaf(a.z, v.z, bb.z)); m.w = fmaxf(m.w, fmaf(a.w, v.w, bb.w));
+            }
+        st4(p + (((size_t)b * Ho + yo) * Wo + xo) * C + c, m);
+    }
+}
+
+// ---- head: BN+ReLU on load, 1x1 conv, softmax, optional probs / argmax / Dice partial sums ---------------
+constexpr int kDiceVals = 5;  // per class: I = sum y*p, T = sum y, P = sum p, Ih = sum y*[p>.5], Ph = sum [p>.5]
+template <int C> struct DiceN { static constexpr int value = (5 * C <= 16) ? 16 : (5 * C <= 32 ? 32 : 64); };
+
+struct HeadFwdArgs {
+    const float* z; const float* ab;   // last conv's raw output + BN record
+    const float* w; const float* bias; // (CIN, C), (C)
+    float* probs; unsigned char* argmax; const unsigned char* labels;
+    float* dice_part;                  // [B][nblk][DiceN]
+    int HW, nblk;
+};
+
+template <int C, int CIN>
+__device__ inline void head_logits(const float* __restrict__ zp, const float* __restrict__ ab,
+                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                   float (&y)[CIN], float (&zr)[CIN], float (&p)[C]) {
+#pragma unroll
+    for (int i = 0; i < CIN; i += 4) {
+        const float4 v = ld4(zp + i);
+        zr[i] = v.x; zr[i + 1] = v.y; zr[i + 2] = v.z; zr[i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) y[i] = fmaxf(fmaf(ab[i], zr[i], ab[CIN + i]), 0.f);
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float l = bias[c];
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) l = fmaf(y[i], w[i * C + c], l);
+        p[c] = l; mx = fmaxf(mx, l);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] = expf(p[c] - mx); sum += p[c]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] *= inv;
+}
+
+template <int C, int CIN>
+__global__ __launch_bounds__(kBlock) void head_fwd_k(const HeadFwdArgs A) {
+    constexpr int N = DiceN<C>::value;
+    __shared__ float red[256];
+    const int b = blockIdx.y;
+    const int px = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = px < A.HW;
+    const size_t pix = (size_t)b * A.HW + (valid ? px : 0);
+    float y[CIN], zr[CIN], p[C];
+    head_logits<C, CIN>(A.z + pix * CIN, A.ab, A.w, A.bias, y, zr, p);
+    if (valid) {
+        if (A.probs) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) A.probs[pix * C + c] = p[c];
+        }
+        if (A.argmax) {
+            int am = 0; float best = p[0];
+#pragma unroll
+            for (int c = 1; c < C; ++c) if (p[c] > best) { best = p[c]; am = c; }  // first maximum, as np.argmax
+            A.argmax[pix] = (unsigned char)am;
+        }
+    }
+    if (A.labels) {
+        float v[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = 0.f;
+        if (valid) {
+            const int lab = A.labels[pix];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float yv = lab == c ? 1.f : 0.f, ph = p[c] > 0.5f ? 1.f : 0.f;
+                v[c * kDiceVals + 0] = yv * p[c]; v[c * kDiceVals + 1] = yv; v[c * kDiceVals + 2] = p[c];
+                v[c * kDiceVals + 3] = yv * ph;   v[c * kDiceVals + 4] = ph;
+            }
+        }
+        block_reduce_store<N>(v, red, A.dice_part + ((size_t)b * A.nblk + blockIdx.x) * N, N);
+    }
+}
+
+// Dice finalize: per-(b,c) sums in fp64 -> losses, metrics, and the per-(b,c) constants backward needs.
+//   out4 = {dice_loss_macro, dice_loss_micro, dice_coef_macro, dice_coef_micro}
+//   bc   = per (b,c): {Num = 2I+s, Den = T+P+s}; then the micro pair at [2*B*C], [2*B*C+1]
+struct DiceFinArgs {
+    const float* part; int B, C, nblk, N;
+    float smooth; float* out4; float* out4_user; double* bc;
+};
+
+__global__ __launch_bounds__(kBlock) void dice_finalize_k(const DiceFinArgs A) {
+    __shared__ double sh[7][kBlock];
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};  // score_macro, coef_macro, I, T, P, Ih, Ph (micro sums)
+    const int n = A.B * A.C;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const int b = i / A.C, c = i % A.C;
+        double v[kDiceVals] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < A.nblk; ++k) {
+            const float* p = A.part + ((size_t)b * A.nblk + k) * A.N + c * kDiceVals;
+            for (int j = 0; j < kDiceVals; ++j) v[j] += p[j];
+        }
+        const double s = A.smooth;
+        const double num = 2.0 * v[0] + s, den = v[1] + v[2] + s;
+        A.bc[2 * i] = num; A.bc[2 * i + 1] = den;
+        acc[0] += num / den;
+        acc[1] += (2.0 * v[3] + 1e-5) / (v[1] + v[4] + 1e-5);   // dice_coef_macro eps (custom_metrics.py:50)
+        acc[2] += v[0]; acc[3] += v[1]; acc[4] += v[2]; acc[5] += v[3]; acc[6] += v[4];
+    }
+    for (int j = 0; j < 7; ++j) sh[j][threadIdx.x] = acc[j];
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) for (int j = 0; j < 7; ++j) sh[j][threadIdx.x] += sh[j][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double s = A.smooth;
+        const double num = 2.0 * sh[2][0] + s, den = sh[3][0] + sh[4][0] + s;
+        A.bc[2 * n] = num; A.bc[2 * n + 1] = den;
+        float o4[4];
+        o4[0] = (float)(1.0 - sh[0][0] / n);
+        o4[1] = (float)(1.0 - num / den);
+        o4[2] = (float)(sh[1][0] / n);
+        o4[3] = (float)(2.0 * sh[5][0] / (sh[3][0] + sh[6][0]));  // no epsilon: 0/0 -> nan as the reference
+        for (int j = 0; j < 4; ++j) { A.out4[j] = o4[j]; if (A.out4_user) A.out4_user[j] = o4[j]; }
+    }
+}
+
+// dropout keep-mask dump for parity tests
+__global__ void dropout_mask_k(unsigned char* out, size_t n, DropCfg d) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = drop_hash(d.seed, d.step, (uint32_t)i) >= d.thresh ? 1 : 0;
+}
+
+}  // namespace oct

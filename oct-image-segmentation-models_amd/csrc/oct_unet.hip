@@ -1,0 +1,645 @@
+// liboct_unet_hip.so -- host plan + C ABI of the MI355X-native OCT U-Net engine.  See include/oct_unet.h.
+// Graph definition follows /root/reference/oct_image_segmentation_models/models/unet.py:106-153.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/oct_unet.h"
+#include "common.hpp"
+#include "kernels_bwd.hpp"
+#include "kernels_fwd.hpp"
+
+using namespace oct;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_OK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) return fail(-5, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+enum Src { SRC_INPUT, SRC_PREV, SRC_POOL, SRC_UP, SRC_CONCAT, SRC_HEAD };
+
+struct Layer {
+    char name[32];
+    int kh, kw, cin, cout, level, H, W, has_bn, src, skip_from, drop_in;
+    size_t w_off, b_off, gamma_off, beta_off, mm_off, mv_off;
+    // workspace (device) pointers
+    float* z = nullptr; float* g = nullptr; float* bn = nullptr;
+};
+
+struct Plan {
+    std::vector<Layer> L;
+    size_t n_params = 0, n_state = 0;
+    int P = 0;
+    std::vector<int> enc_last;  // per level: conv index whose output is pooled + skip-concatenated
+};
+
+int check_cfg(const oct_unet_cfg* c) {
+    if (!c) return fail(-1, "null cfg");
+    if (c->in_ch < 1) return fail(-1, "in_ch must be >= 1");
+    if (c->n_cls < 2 || c->n_cls > 8) return fail(-1, "n_cls must be in 2..8");
+    if (c->pool_layers < 1 || c->pool_layers > 6) return fail(-1, "pool_layers must be in 1..6");
+    if (c->conv_layers < 1) return fail(-1, "conv_layers must be >= 1");
+    if (c->start_neurons != 4 && c->start_neurons != 8 && c->start_neurons != 16)
+        return fail(-1, "start_neurons must be 4, 8 or 16");
+    if (c->enc_k != 3 || c->dec_k != 2) return fail(-1, "only enc_kernel (3,3) / dec_kernel (2,2) are implemented");
+    const int m = 1 << c->pool_layers;
+    if (c->H < m || c->W < m || c->H % m || c->W % m) return fail(-1, "H and W must be multiples of 2^pool_layers");
+    if (c->max_batch < 1) return fail(-1, "max_batch must be >= 1");
+    if (c->dtype != 0) return fail(-2, "dtype: only 0 (f32) is implemented");
+    if (!(c->dropout_rate >= 0.f && c->dropout_rate < 1.f)) return fail(-1, "dropout_rate must be in [0,1)");
+    if ((size_t)c->max_batch * c->H * c->W * (size_t)(c->start_neurons << c->pool_layers) >= (1ull << 32))
+        return fail(-1, "tensor too large for 32-bit dropout indexing");
+    return 0;
+}
+
+Plan build_plan(const oct_unet_cfg& c) {
+    Plan pl; pl.P = c.pool_layers;
+    const int sn = c.start_neurons, P = c.pool_layers, Lc = c.conv_layers;
+    int cin = c.in_ch;
+    auto add = [&](const std::string& nm, int k, int ci, int co, int lvl, int bn, int src, int skip) {
+        Layer l{}; snprintf(l.name, sizeof l.name, "%s", nm.c_str());
+        l.kh = l.kw = k; l.cin = ci; l.cout = co; l.level = lvl; l.H = c.H >> lvl; l.W = c.W >> lvl;
+        l.has_bn = bn; l.src = src; l.skip_from = skip; l.drop_in = 0;
+        l.w_off = pl.n_params; pl.n_params += (size_t)k * k * ci * co;
+        l.b_off = pl.n_params; pl.n_params += co;
+        if (bn) {
+            l.gamma_off = pl.n_params; pl.n_params += co;
+            l.beta_off = pl.n_params; pl.n_params += co;
+            l.mm_off = pl.n_state; pl.n_state += co;
+            l.mv_off = pl.n_state; pl.n_state += co;
+        }
+        pl.L.push_back(l);
+    };
+    for (int i = 0; i < P; ++i) {
+        const int size = sn << i;
+        for (int j = 0; j < Lc; ++j) {
+            const int src = (i == 0 && j == 0) ? SRC_INPUT : (j == 0 ? SRC_POOL : SRC_PREV);
+            add("enc" + std::to_string(i) + ".conv" + std::to_string(j), c.enc_k, cin, size, i, 1, src, -1);
+            cin = size;
+        }
+        pl.enc_last.push_back((int)pl.L.size() - 1);
+    }
+    for (int j = 0; j < Lc; ++j) {
+        add("mid.conv" + std::to_string(j), c.enc_k, cin, sn << P, P, 1, j == 0 ? SRC_POOL : SRC_PREV, -1);
+        cin = sn << P;
+    }
+    for (int i = 0; i < P; ++i) {
+        const int lvl = P - 1 - i, size = sn << lvl;
+        add("dec" + std::to_string(i) + ".up", c.dec_k, cin, size, lvl, 1, SRC_UP, -1);
+        if (i == 0 && c.dropout_rate > 0.f) pl.L.back().drop_in = 1;  // Dropout(0.5) sits on the bottleneck output
+        cin = 2 * size;
+        for (int j = 0; j < Lc; ++j) {
+            add("dec" + std::to_string(i) + ".conv" + std::to_string(j), c.enc_k, cin, size, lvl, 1,
+                j == 0 ? SRC_CONCAT : SRC_PREV, j == 0 ? pl.enc_last[lvl] : -1);
+            cin = size;
+        }
+    }
+    add("head", 1, cin, c.n_cls, 0, 0, SRC_HEAD, -1);
+    return pl;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int tiles_of(int H, int W) { return cdiv(H, kTileY) * cdiv(W, kTileX); }
+inline int chunk_of(int c) { return c % 16 == 0 ? 16 : (c % 8 == 0 ? 8 : 4); }   // channel chunk per thread
+
+// dW pixel-block count: enough blocks to fill 256 CUs a few times over, never more than the tile count
+int dw_npb(const Layer& l, int B, int ci_t, int co_t) {
+    const int chunks = cdiv(l.cin, ci_t) * cdiv(l.cout, co_t);
+    const int total = B * tiles_of(l.H, l.W);
+    int npb = cdiv(2048, chunks);
+    if (npb > total) npb = total;
+    return npb < 1 ? 1 : npb;
+}
+inline int dw_ci_t(const Layer& l) { return l.cin % 4 ? 1 : chunk_of(l.cin); }
+inline int dw_co_t(const Layer& l) { return l.cout % 4 ? (l.cout <= 4 ? 4 : 8) : chunk_of(l.cout); }
+
+}  // namespace
+
+struct oct_unet {
+    oct_unet_cfg cfg;
+    Plan plan;
+    float* params; float* grads; float* state;
+    std::vector<float*> pooled, gpooled;   // per encoder level
+    float* stat_part = nullptr;            // BN statistic partials (fwd and bwd share it: stream-ordered)
+    float* dw_part = nullptr;
+    float* dice_part = nullptr; double* dice_bc = nullptr; float* loss4 = nullptr;
+    float* dlogits = nullptr;
+    unsigned long long drop_step = 0;
+    int last_B = 0; int last_training = 0; int have_dice = 0; int dice_final = 0;
+    const void* last_x = nullptr; int last_u8 = 0;   // input of the last forward (first layer's dW re-reads it)
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+};
+
+namespace {
+
+// Carve the workspace; with base == nullptr only sizes are computed.  Returns total bytes.
+size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> char* { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    const size_t B = (size_t)c.max_batch;
+    size_t stat_max = 0, dw_max = 0;
+    for (auto& l : pl.L) {
+        const size_t n = B * l.H * l.W * l.cout;
+        float* z = l.has_bn ? (float*)take(n * 4) : nullptr;   // the head writes straight to the caller's buffers
+        float* g = c.training && l.has_bn ? (float*)take(n * 4) : nullptr;
+        float* bn = l.has_bn ? (float*)take((size_t)BN_ARRAYS * l.cout * 4) : nullptr;
+        if (base) { l.z = z; l.g = g; l.bn = bn; }
+        stat_max = std::max(stat_max, B * tiles_of(l.H, l.W) * 2 * (size_t)std::max(l.cout, l.cin));
+        if (c.training) {
+            const size_t wsz = (size_t)l.kh * l.kw * l.cin * l.cout + l.cout;
+            dw_max = std::max(dw_max, (size_t)dw_npb(l, c.max_batch, dw_ci_t(l), dw_co_t(l)) * wsz);
+        }
+    }
+    for (int i = 0; i < pl.P; ++i) {
+        const size_t n = B * (c.H >> (i + 1)) * (c.W >> (i + 1)) * ((size_t)c.start_neurons << i);
+        float* p = (float*)take(n * 4);
+        float* gp = c.training ? (float*)take(n * 4) : nullptr;
+        if (h) { h->pooled.push_back(p); h->gpooled.push_back(gp); }
+    }
+    const int nblk_head = cdiv(c.H * c.W, kBlock);
+    stat_max = std::max(stat_max, B * nblk_head * 2 * (size_t)c.start_neurons);
+    float* sp = (float*)take(stat_max * 4);
+    float* dwp = c.training ? (float*)take(dw_max * 4) : nullptr;
+    float* dp = (float*)take(B * nblk_head * 64 * 4);
+    double* bc = (double*)take((B * 8 * 2 + 2) * 8);
+    float* l4 = (float*)take(4 * 4);
+    float* dl = c.training ? (float*)take(B * c.H * c.W * c.n_cls * 4) : nullptr;
+    if (h) { h->stat_part = sp; h->dw_part = dwp; h->dice_part = dp; h->dice_bc = bc; h->loss4 = l4; h->dlogits = dl; }
+    return off;
+}
+
+DropCfg make_drop(const oct_unet* h) {
+    DropCfg d;
+    d.seed = h->cfg.seed; d.step = h->drop_step;
+    const double r = h->cfg.dropout_rate;
+    d.thresh = (unsigned)std::min(4294967295.0, std::floor(r * 4294967296.0));
+    d.scale = (float)(1.0 / (1.0 - r));
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward launches
+// ---------------------------------------------------------------------------------------------------------------
+template <int KH, int FLAGS>
+int launch_conv_fwd_co(const ConvFwdArgs& a, int B, hipStream_t s) {
+    const int co_t = chunk_of(a.Cout);
+    dim3 grid(a.tiles, a.Cout / co_t, B), block(kBlock);
+    switch (co_t) {
+        case 16: conv_fwd_k<KH, 16, FLAGS><<<grid, block, 0, s>>>(a); break;
+        case 8: conv_fwd_k<KH, 8, FLAGS><<<grid, block, 0, s>>>(a); break;
+        default: conv_fwd_k<KH, 4, FLAGS><<<grid, block, 0, s>>>(a); break;
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// source description of layer li's input (shared by forward conv and dW)
+struct SrcDesc { const void* x0; const float* ab0; int C0; const float* x1; const float* ab1; int C1; int flags; };
+
+SrcDesc src_of(const oct_unet* h, int li, const void* x_in, int x_is_u8) {
+    const Layer& l = h->plan.L[li];
+    SrcDesc d{}; d.x1 = nullptr; d.ab1 = nullptr; d.C1 = 0;
+    switch (l.src) {
+        case SRC_INPUT: d.x0 = x_in; d.ab0 = nullptr; d.C0 = l.cin; d.flags = x_is_u8 ? F_U8 : 0; break;
+        case SRC_PREV: case SRC_HEAD: { const Layer& p = h->plan.L[li - 1]; d.x0 = p.z; d.ab0 = p.bn; d.C0 = p.cout; d.flags = F_AFF; break; }
+        case SRC_POOL: d.x0 = h->pooled[l.level - 1]; d.ab0 = nullptr; d.C0 = l.cin; d.flags = 0; break;
+        case SRC_UP: { const Layer& p = h->plan.L[li - 1]; d.x0 = p.z; d.ab0 = p.bn; d.C0 = p.cout; d.flags = F_AFF | F_UP; break; }
+        case SRC_CONCAT: {
+            const Layer& p = h->plan.L[li - 1]; const Layer& k = h->plan.L[l.skip_from];
+            d.x0 = p.z; d.ab0 = p.bn; d.C0 = p.cout; d.x1 = k.z; d.ab1 = k.bn; d.C1 = k.cout; d.flags = F_AFF | F_TWO; break;
+        }
+    }
+    return d;
+}
+
+int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int training, hipStream_t s) {
+    Layer& l = h->plan.L[li];
+    const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
+    ConvFwdArgs a{};
+    a.x0 = sd.x0; a.ab0 = sd.ab0; a.C0 = sd.C0; a.x1 = sd.x1; a.ab1 = sd.ab1; a.C1 = sd.C1;
+    a.w = h->params + l.w_off; a.bias = h->params + l.b_off; a.z = l.z;
+    a.part = (training && l.has_bn) ? h->stat_part : nullptr;
+    a.H = l.H; a.W = l.W; a.Cin = l.cin; a.Cout = l.cout;
+    a.tiles_x = cdiv(l.W, kTileX); a.tiles = tiles_of(l.H, l.W);
+    a.drop = make_drop(h);
+    const bool drop = training && l.drop_in;
+    int rc;
+    switch (l.src) {
+        case SRC_INPUT: rc = x_is_u8 ? launch_conv_fwd_co<3, F_U8>(a, B, s) : launch_conv_fwd_co<3, 0>(a, B, s); break;
+        case SRC_POOL: rc = launch_conv_fwd_co<3, 0>(a, B, s); break;
+        case SRC_PREV: rc = launch_conv_fwd_co<3, F_AFF>(a, B, s); break;
+        case SRC_CONCAT: rc = launch_conv_fwd_co<3, F_AFF | F_TWO>(a, B, s); break;
+        case SRC_UP: rc = drop ? launch_conv_fwd_co<2, F_AFF | F_UP | F_DROP>(a, B, s) : launch_conv_fwd_co<2, F_AFF | F_UP>(a, B, s); break;
+        default: return fail(-3, "conv_forward: bad src");
+    }
+    if (rc) return rc;
+    if (l.has_bn && training) {
+        BnFinArgs f{};
+        f.part = h->stat_part; f.nblk = B * a.tiles; f.C = l.cout; f.count = (double)B * l.H * l.W;
+        f.gamma = h->params + l.gamma_off; f.beta = h->params + l.beta_off; f.bn = l.bn;
+        f.mm = h->state + l.mm_off; f.mv = h->state + l.mv_off;
+        f.eps = h->cfg.bn_eps; f.momentum = h->cfg.bn_momentum; f.unbiased = h->cfg.bn_unbiased_moving_var;
+        bn_fwd_finalize_k<<<l.cout, kBlock, 0, s>>>(f);
+        HIP_OK(hipGetLastError());
+    }
+    return 0;
+}
+
+template <int C>
+int launch_head_fwd(const HeadFwdArgs& a, int cin, int B, hipStream_t s) {
+    dim3 grid(a.nblk, B), block(kBlock);
+    switch (cin) {
+        case 4: head_fwd_k<C, 4><<<grid, block, 0, s>>>(a); break;
+        case 8: head_fwd_k<C, 8><<<grid, block, 0, s>>>(a); break;
+        case 16: head_fwd_k<C, 16><<<grid, block, 0, s>>>(a); break;
+        default: return fail(-3, "head: unsupported start_neurons");
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <int C>
+int launch_head_bwd(const HeadBwdArgs& a, int cin, int B, hipStream_t s) {
+    dim3 grid(a.nblk, B), block(kBlock);
+    switch (cin) {
+        case 4: head_bwd_k<C, 4><<<grid, block, 0, s>>>(a); break;
+        case 8: head_bwd_k<C, 8><<<grid, block, 0, s>>>(a); break;
+        case 16: head_bwd_k<C, 16><<<grid, block, 0, s>>>(a); break;
+        default: return fail(-3, "head: unsupported start_neurons");
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+#define DISPATCH_C(fn, ncls, ...)                       \
+    ([&]() -> int {                                     \
+        switch (ncls) {                                 \
+            case 2: return fn<2>(__VA_ARGS__);          \
+            case 3: return fn<3>(__VA_ARGS__);          \
+            case 4: return fn<4>(__VA_ARGS__);          \
+            case 5: return fn<5>(__VA_ARGS__);          \
+            case 6: return fn<6>(__VA_ARGS__);          \
+            case 7: return fn<7>(__VA_ARGS__);          \
+            case 8: return fn<8>(__VA_ARGS__);          \
+            default: return fail(-3, "bad n_cls");      \
+        }                                               \
+    })()
+
+int dice_n(int C) { return 5 * C <= 16 ? 16 : (5 * C <= 32 ? 32 : 64); }
+
+int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, const oct_unet_io* io, hipStream_t s) {
+    Plan& pl = h->plan;
+    const int nl = (int)pl.L.size();
+    if (!training) {  // (a, b) from moving statistics
+        for (auto& l : pl.L)
+            if (l.has_bn) {
+                bn_infer_coeffs_k<<<cdiv(l.cout, 64), 64, 0, s>>>(h->params + l.gamma_off, h->params + l.beta_off,
+                                                                  h->state + l.mm_off, h->state + l.mv_off, l.bn, l.cout, h->cfg.bn_eps);
+            }
+        HIP_OK(hipGetLastError());
+    }
+    for (int li = 0; li < nl - 1; ++li) {
+        Layer& l = pl.L[li];
+        if (l.src == SRC_POOL) {  // pool the previous block's output (BN+ReLU applied on load)
+            const Layer& p = pl.L[li - 1];
+            const size_t n = (size_t)B * (p.H / 2) * (p.W / 2) * (p.cout / 4);
+            const int grid = (int)std::min<size_t>((n + kBlock - 1) / kBlock, 8192);
+            pool_fwd_k<<<grid, kBlock, 0, s>>>(p.z, p.bn, h->pooled[l.level - 1], B, p.H, p.W, p.cout);
+            HIP_OK(hipGetLastError());
+        }
+        const int rc = conv_forward(h, li, x, x_is_u8, B, training, s);
+        if (rc) return rc;
+    }
+    // head
+    const Layer& hd = pl.L[nl - 1]; const Layer& last = pl.L[nl - 2];
+    HeadFwdArgs a{};
+    a.z = last.z; a.ab = last.bn; a.w = h->params + hd.w_off; a.bias = h->params + hd.b_off;
+    a.probs = io ? io->probs : nullptr; a.argmax = io ? io->argmax : nullptr; a.labels = io ? io->labels : nullptr;
+    a.dice_part = h->dice_part; a.HW = hd.H * hd.W; a.nblk = cdiv(a.HW, kBlock);
+    const int rc = DISPATCH_C(launch_head_fwd, h->cfg.n_cls, a, hd.cin, B, s);
+    if (rc) return rc;
+    h->last_B = B; h->last_training = training; h->have_dice = a.labels != nullptr;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward launches
+// ---------------------------------------------------------------------------------------------------------------
+template <int KH>
+int launch_dw(const ConvBwdWArgs& a, int ci_t, int co_t, hipStream_t s) {
+    dim3 grid(a.npb, cdiv(a.Cin, ci_t), cdiv(a.Cout, co_t)), block(kBlock);
+#define DW_CASE(CI, CO) if (ci_t == CI && co_t == CO) { conv_bwd_w_k<KH, CI, CO><<<grid, block, 0, s>>>(a); HIP_OK(hipGetLastError()); return 0; }
+    DW_CASE(1, 4) DW_CASE(1, 8) DW_CASE(1, 16)
+    DW_CASE(4, 4) DW_CASE(4, 8) DW_CASE(4, 16)
+    DW_CASE(8, 4) DW_CASE(8, 8) DW_CASE(8, 16)
+    DW_CASE(16, 4) DW_CASE(16, 8) DW_CASE(16, 16)
+#undef DW_CASE
+    return fail(-3, "dW: unsupported channel chunking");
+}
+
+int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const float* dz, int B, hipStream_t s) {
+    const Layer& l = h->plan.L[li];
+    const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
+    ConvBwdWArgs a{};
+    a.x0 = sd.x0; a.ab0 = sd.ab0; a.C0 = sd.C0; a.x1 = sd.x1; a.ab1 = sd.ab1; a.C1 = sd.C1;
+    a.flags = sd.flags | (l.drop_in ? F_DROP : 0);
+    a.dz = dz; a.part = h->dw_part;
+    a.B = B; a.H = l.H; a.W = l.W; a.Cin = l.cin; a.Cout = l.cout;
+    a.tiles_x = cdiv(l.W, kTileX); a.tiles = tiles_of(l.H, l.W); a.total_tiles = B * a.tiles;
+    const int ci_t = dw_ci_t(l), co_t = dw_co_t(l);
+    a.npb = dw_npb(l, B, ci_t, co_t);
+    a.drop = make_drop(h);
+    int rc;
+    switch (l.kh) {
+        case 1: rc = launch_dw<1>(a, ci_t, co_t, s); break;
+        case 2: rc = launch_dw<2>(a, ci_t, co_t, s); break;
+        default: rc = launch_dw<3>(a, ci_t, co_t, s); break;
+    }
+    if (rc) return rc;
+    const size_t wsize = (size_t)l.kh * l.kw * l.cin * l.cout, stride = wsize + l.cout;
+    reduce_partials_k<<<(int)((stride + kBlock - 1) / kBlock), kBlock, 0, s>>>(h->dw_part, a.npb, stride, wsize,
+                                                                              h->grads + l.w_off, h->grads + l.b_off);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <int KH, bool UP, int EPI>
+int launch_dx(const ConvBwdDataArgs& a, int B, hipStream_t s) {
+    const int ci_t = std::min(chunk_of(a.Cg), 8);
+    dim3 grid(a.tiles, a.Cg / ci_t, B), block(kBlock);
+    if (ci_t == 8) conv_bwd_data_k<KH, 8, UP, EPI><<<grid, block, 0, s>>>(a);
+    else conv_bwd_data_k<KH, 4, UP, EPI><<<grid, block, 0, s>>>(a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// finalize + apply BN backward for block li (its g buffer holds masked gradients, stat_part the partials)
+int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s) {
+    const Layer& l = h->plan.L[li];
+    BnBwdFinArgs f{};
+    f.part = h->stat_part; f.nblk = nblk; f.C = l.cout; f.count = (double)B * l.H * l.W;
+    f.bn = l.bn; f.dgamma = h->grads + l.gamma_off; f.dbeta = h->grads + l.beta_off;
+    bn_bwd_finalize_k<<<l.cout, kBlock, 0, s>>>(f);
+    const size_t n4 = (size_t)B * l.H * l.W * l.cout / 4;
+    const int grid = (int)std::min<size_t>((n4 + kBlock - 1) / kBlock, 8192);
+    bn_bwd_apply_k<<<grid, kBlock, 0, s>>>(l.g, l.z, l.bn, h->params + l.gamma_off, n4, l.cout);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned char* labels, int macro, float loss_scale, hipStream_t s) {
+    Plan& pl = h->plan;
+    const int nl = (int)pl.L.size(), B = h->last_B;
+    const Layer& hd = pl.L[nl - 1]; const Layer& last = pl.L[nl - 2];
+    // head: dlogits, masked gradient of the last block + its statistics
+    HeadBwdArgs hb{};
+    hb.z = last.z; hb.bn = last.bn; hb.w = h->params + hd.w_off; hb.bias = h->params + hd.b_off;
+    hb.labels = labels; hb.bc = h->dice_bc; hb.dlogits = h->dlogits; hb.g = last.g; hb.part = h->stat_part;
+    hb.HW = hd.H * hd.W; hb.nblk = cdiv(hb.HW, kBlock); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale;
+    int rc = DISPATCH_C(launch_head_bwd, h->cfg.n_cls, hb, hd.cin, B, s);
+    if (rc) return rc;
+    int pending_nblk = B * hb.nblk;           // number of stat partial rows waiting for block (li-1)
+    rc = conv_backward_w(h, nl - 1, x_in, x_is_u8, h->dlogits, B, s);
+    if (rc) return rc;
+
+    for (int li = nl - 2; li >= 0; --li) {
+        Layer& l = pl.L[li];
+        // g buffer of block li is complete (+ partials in stat_part) -> dz in place
+        rc = bn_backward(h, li, pending_nblk, B, s);
+        if (rc) return rc;
+        rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s);
+        if (rc) return rc;
+        if (l.src == SRC_INPUT) break;
+        ConvBwdDataArgs a{};
+        a.dz = l.g; a.w = h->params + l.w_off; a.Cin_total = l.cin; a.Cout = l.cout; a.H = l.H; a.W = l.W;
+        a.drop = make_drop(h); a.accumulate = 0;
+        auto set_out = [&](float* g, int Cg, int ci_off, int Hg, int Wg, const Layer* prod) {
+            a.g = g; a.Cg = Cg; a.ci_off = ci_off; a.Hg = Hg; a.Wg = Wg;
+            a.tiles_x = cdiv(Wg, kTileX); a.tiles = tiles_of(Hg, Wg);
+            a.zin = prod ? prod->z : nullptr; a.bnin = prod ? prod->bn : nullptr; a.part = h->stat_part;
+        };
+        switch (l.src) {
+            case SRC_PREV: {
+                Layer& p = pl.L[li - 1];
+                set_out(p.g, p.cout, 0, l.H, l.W, &p);
+                rc = launch_dx<3, false, E_MASK>(a, B, s);
+                pending_nblk = B * a.tiles;
+                break;
+            }
+            case SRC_POOL: {  // gradient wrt the pooled tensor (raw), then route through the pool into block li-1
+                Layer& p = pl.L[li - 1];
+                set_out(h->gpooled[l.level - 1], l.cin, 0, l.H, l.W, nullptr);
+                rc = launch_dx<3, false, E_RAW>(a, B, s);
+                if (rc) return rc;
+                PoolBwdArgs pb{};
+                pb.gp = h->gpooled[l.level - 1]; pb.z = p.z; pb.bn = p.bn; pb.g = p.g; pb.part = h->stat_part;
+                pb.H = p.H; pb.W = p.W; pb.C = p.cout; pb.tiles_x = cdiv(p.W / 2, kTileX); pb.tiles = tiles_of(p.H / 2, p.W / 2);
+                const int c_t = std::min(chunk_of(p.cout), 8);
+                dim3 grid(pb.tiles, p.cout / c_t, B);
+                if (c_t == 8) pool_bwd_k<8><<<grid, kBlock, 0, s>>>(pb); else pool_bwd_k<4><<<grid, kBlock, 0, s>>>(pb);
+                HIP_OK(hipGetLastError());
+                pending_nblk = B * pb.tiles;
+                break;
+            }
+            case SRC_UP: {
+                Layer& p = pl.L[li - 1];
+                set_out(p.g, p.cout, 0, l.H / 2, l.W / 2, &p);
+                rc = l.drop_in ? launch_dx<2, true, E_MASK_DROP>(a, B, s) : launch_dx<2, true, E_MASK>(a, B, s);
+                pending_nblk = B * a.tiles;
+                break;
+            }
+            case SRC_CONCAT: {
+                Layer& p = pl.L[li - 1]; Layer& k = pl.L[l.skip_from];
+                // skip half first (raw, merged later by pool_bwd of that encoder level) ...
+                set_out(k.g, k.cout, p.cout, l.H, l.W, nullptr);
+                rc = launch_dx<3, false, E_RAW>(a, B, s);
+                if (rc) return rc;
+                // ... then the up-path half, whose statistics must be the ones pending for block li-1
+                set_out(p.g, p.cout, 0, l.H, l.W, &p);
+                rc = launch_dx<3, false, E_MASK>(a, B, s);
+                pending_nblk = B * a.tiles;
+                break;
+            }
+            default: return fail(-3, "backward: bad src");
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+const char* oct_last_error(void) { return g_err.c_str(); }
+const char* oct_version(void) { return "oct_unet_hip 0.1 (gfx950)"; }
+
+void oct_unet_cfg_default(oct_unet_cfg* c) {
+    if (!c) return;
+    memset(c, 0, sizeof *c);
+    c->in_ch = 1; c->n_cls = 3; c->H = 256; c->W = 512; c->max_batch = 1;
+    c->start_neurons = 8; c->pool_layers = 4; c->conv_layers = 2; c->enc_k = 3; c->dec_k = 2;
+    c->dtype = 0; c->training = 0; c->bn_eps = 1e-3f; c->bn_momentum = 0.99f; c->dropout_rate = 0.5f;
+    c->bn_unbiased_moving_var = 1; c->seed = 0x0C7ull;
+}
+
+int oct_unet_cfg_check(const oct_unet_cfg* c) { return check_cfg(c); }
+
+size_t oct_unet_param_count(const oct_unet_cfg* c) { return check_cfg(c) ? 0 : build_plan(*c).n_params; }
+size_t oct_unet_state_count(const oct_unet_cfg* c) { return check_cfg(c) ? 0 : build_plan(*c).n_state; }
+int oct_unet_layer_count(const oct_unet_cfg* c) { return check_cfg(c) ? -1 : (int)build_plan(*c).L.size(); }
+
+size_t oct_unet_workspace_bytes(const oct_unet_cfg* c) {
+    if (check_cfg(c)) return 0;
+    Plan pl = build_plan(*c);
+    return carve(*c, pl, nullptr, nullptr);
+}
+
+int oct_unet_layer_info(const oct_unet_cfg* c, int index, oct_layer_info* out) {
+    if (int rc = check_cfg(c)) return rc;
+    if (!out) return fail(-1, "null out");
+    Plan pl = build_plan(*c);
+    if (index < 0 || index >= (int)pl.L.size()) return fail(-1, "layer index out of range");
+    const Layer& l = pl.L[index];
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", l.name);
+    out->kh = l.kh; out->kw = l.kw; out->cin = l.cin; out->cout = l.cout; out->has_bn = l.has_bn;
+    out->out_h = l.H; out->out_w = l.W;
+    out->kernel_off = l.w_off; out->bias_off = l.b_off; out->gamma_off = l.gamma_off; out->beta_off = l.beta_off;
+    out->moving_mean_off = l.mm_off; out->moving_var_off = l.mv_off;
+    return 0;
+}
+
+int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* state, void* ws, size_t ws_bytes,
+                    oct_unet** out) {
+    if (int rc = check_cfg(c)) return rc;
+    if (!out || !params || !state || !ws) return fail(-1, "null pointer argument");
+    if (c->training && !grads) return fail(-1, "training handle needs a grads buffer");
+    oct_unet* h = new oct_unet();
+    h->cfg = *c; h->plan = build_plan(*c);
+    h->params = params; h->grads = grads; h->state = state;
+    const size_t need = carve(*c, h->plan, nullptr, nullptr);
+    if (ws_bytes < need) { delete h; return fail(-4, "workspace too small: need " + std::to_string(need) + " bytes"); }
+    if (((uintptr_t)ws & 255) || ((uintptr_t)params & 15) || ((uintptr_t)state & 15) || (grads && ((uintptr_t)grads & 15))) {
+        delete h; return fail(-1, "buffers must be aligned (workspace 256 B, params/grads/state 16 B)");
+    }
+    carve(*c, h->plan, h, (char*)ws);
+    float lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_u8_lut), lut, sizeof lut);
+    if (e != hipSuccess) { delete h; return fail(-5, std::string("hipMemcpyToSymbol: ") + hipGetErrorString(e)); }
+    *out = h;
+    return 0;
+}
+
+void oct_unet_destroy(oct_unet* h) {
+    if (!h) return;
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    delete h;
+}
+
+int oct_unet_forward(oct_unet* h, const void* x, int x_is_u8, int B, int training, const oct_unet_io* io, oct_stream_t stream) {
+    if (!h || !x) return fail(-1, "null handle or input");
+    if (B < 1 || B > h->cfg.max_batch) return fail(-1, "B out of range (1..max_batch)");
+    if (training && !h->cfg.training) return fail(-1, "handle was created without training workspaces");
+    const int rc = forward_impl(h, x, x_is_u8, B, training, io, (hipStream_t)stream);
+    if (rc) return rc;
+    h->last_x = x; h->last_u8 = x_is_u8; h->dice_final = 0;
+    return 0;
+}
+
+int oct_unet_loss_dice(oct_unet* h, float smooth, float* out4, oct_stream_t stream) {
+    if (!h) return fail(-1, "null handle");
+    if (!h->have_dice) return fail(-1, "loss_dice needs a preceding forward with io.labels");
+    DiceFinArgs a{};
+    a.part = h->dice_part; a.B = h->last_B; a.C = h->cfg.n_cls; a.nblk = cdiv(h->cfg.H * h->cfg.W, kBlock);
+    a.N = dice_n(a.C); a.smooth = smooth; a.out4 = h->loss4; a.out4_user = out4; a.bc = h->dice_bc;
+    dice_finalize_k<<<1, kBlock, 0, (hipStream_t)stream>>>(a);
+    HIP_OK(hipGetLastError());
+    h->dice_final = 1;
+    return 0;
+}
+
+int oct_unet_backward(oct_unet* h, const unsigned char* labels, int macro, float loss_scale, oct_stream_t stream) {
+    if (!h || !labels) return fail(-1, "null handle or labels");
+    if (!h->last_training || !h->have_dice || !h->dice_final)
+        return fail(-1, "backward needs a training forward with io.labels followed by oct_unet_loss_dice");
+    return backward_impl(h, h->last_x, h->last_u8, labels, macro, loss_scale, (hipStream_t)stream);
+}
+
+int oct_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                  long step, oct_stream_t stream) {
+    if (!p || !g || !m || !v || step < 1) return fail(-1, "adam: bad arguments");
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)b2, (double)step)) / (1.0 - std::pow((double)b1, (double)step));
+    const int grid = (int)std::min<size_t>((n + kBlock - 1) / kBlock, 4096);
+    adam_k<<<grid, kBlock, 0, (hipStream_t)stream>>>(p, g, m, v, n, (float)lr_t, b1, b2, eps);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int oct_sgd_step(float* p, const float* g, float* mom, size_t n, float lr, float momentum, oct_stream_t stream) {
+    if (!p || !g) return fail(-1, "sgd: bad arguments");
+    const int grid = (int)std::min<size_t>((n + kBlock - 1) / kBlock, 4096);
+    sgd_k<<<grid, kBlock, 0, (hipStream_t)stream>>>(p, g, mom, n, lr, momentum);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int oct_unet_set_dropout_step(oct_unet* h, unsigned long long step) {
+    if (!h) return fail(-1, "null handle");
+    h->drop_step = step;
+    return 0;
+}
+
+int oct_unet_dropout_mask(oct_unet* h, int B, unsigned char* mask, oct_stream_t stream) {
+    if (!h || !mask) return fail(-1, "null argument");
+    const int P = h->cfg.pool_layers;
+    const size_t n = (size_t)B * (h->cfg.H >> P) * (h->cfg.W >> P) * ((size_t)h->cfg.start_neurons << P);
+    dropout_mask_k<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256, 0, (hipStream_t)stream>>>(mask, n, make_drop(h));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int oct_unet_graph_capture(oct_unet* h, const void* x, int x_is_u8, int B, const oct_unet_io* io, oct_stream_t stream) {
+    if (!h || !x) return fail(-1, "null handle or input");
+    if (B < 1 || B > h->cfg.max_batch) return fail(-1, "B out of range (1..max_batch)");
+    hipStream_t s = (hipStream_t)stream;
+    if (!s) return fail(-1, "graph capture needs a non-default stream");
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = forward_impl(h, x, x_is_u8, B, 0, io, s);
+    hipError_t e = hipStreamEndCapture(s, &h->graph);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(-5, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    HIP_OK(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    return 0;
+}
+
+int oct_unet_graph_launch(oct_unet* h, oct_stream_t stream) {
+    if (!h || !h->graph_exec) return fail(-1, "no captured graph");
+    HIP_OK(hipGraphLaunch(h->graph_exec, (hipStream_t)stream));
+    return 0;
+}
+
+const float* oct_unet_debug_activation(oct_unet* h, int layer, int which) {
+    if (!h || layer < 0 || layer >= (int)h->plan.L.size()) return nullptr;
+    return which == 0 ? h->plan.L[layer].z : h->plan.L[layer].g;
+}
+
+}  // extern "C"

@@ -491,6 +491,7 @@ def backward(cfg: UNetConfig, params, cache, labels: np.ndarray, macro: bool = T
             dgamma = (g * c["xhat"]).sum(axis=(0, 1, 2))
             dz = p["gamma"] * c["rstd"] * (g - dbeta / n - c["xhat"] * dgamma / n)
             grads[li]["gamma"], grads[li]["beta"] = dgamma, dbeta
+        c["dz"] = dz  # kept for layer-wise checks of the device path
         gx, dk, db = _conv_backward(c["x"], p["kernel"], dz)
         grads[li]["kernel"], grads[li]["bias"] = dk, db
         if spec.src == "input":

@@ -1,0 +1,225 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star): per-pixel probabilities within 1e-4 (fp32 path vs the fp64 oracle on fp32-rounded
+weights), Dice within 1e-3; gradients within 2e-4 of the layer's largest gradient entry.
+PARITY UNPINNED vs TensorFlow 2.9 itself -- see oracle/unet_numpy.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_numpy as on
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-4
+DICE_TOL = 1e-3
+GRAD_RTOL = 2e-4
+
+
+def make(B, H, W, C, sn, P, L=2, in_ch=1, seed=0, training=True, max_batch=None):
+    from oct_image_segmentation_models_amd.engine import UNetEngine
+    cfg = on.UNetConfig(input_channels=in_ch, num_classes=C, start_neurons=sn, pool_layers=P, conv_layers=L)
+    params, state = on.init_params(cfg, seed=seed, dtype=np.float32, randomize_bn=True)
+    eng = UNetEngine(device="cuda:0", input_channels=in_ch, num_classes=C, image_height=H, image_width=W,
+                     start_neurons=sn, pool_layers=P, conv_layers=L, max_batch=max_batch or B, training=training,
+                     seed=seed + 100)
+    eng.set_weights(on.keras_weight_list(params, state))
+    p64 = [{k: v.astype(np.float64) for k, v in p.items()} for p in params]
+    s64 = [{k: v.astype(np.float64) for k, v in s.items()} for s in state]
+    return cfg, eng, p64, s64
+
+
+def data(B, H, W, C, in_ch=1, seed=5):
+    images, labels = on.synth_scans(B, H, W, C, seed=seed)
+    if in_ch > 1:
+        rng = np.random.default_rng(seed)
+        images = rng.integers(0, 256, (B, H, W, in_ch)).astype(np.uint8)
+    return images, labels
+
+
+CASES = [
+    # B, H, W, C, sn, P, L, in_ch
+    (2, 32, 64, 3, 8, 2, 2, 1),
+    (3, 16, 32, 4, 4, 2, 2, 1),
+    (1, 48, 80, 3, 8, 3, 1, 3),     # ragged tiles (48x80 not multiples of the 8x32 thread tile), 3 input channels
+    (2, 64, 64, 2, 16, 1, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_inference_forward_matches_oracle(case):
+    B, H, W, C, sn, P, L, ic = case
+    cfg, eng, p64, s64 = make(B, H, W, C, sn, P, L, ic, training=False)
+    images, labels = data(B, H, W, C, ic)
+    x = torch.from_numpy(images).cuda()
+    probs, am = eng.forward(x, training=False, want_argmax=True)
+    ref, cache = on.forward(cfg, p64, s64, on.preprocess_u8(images, np.float64), training=False)
+    # layer-wise first: names the first diverging layer
+    for li, spec in enumerate(on.build_plan(cfg)[:-1]):
+        z = eng.debug_activation(li, 0)[:B].cpu().numpy()
+        scale = max(1.0, np.abs(cache[li]["z"]).max())
+        assert np.abs(z - cache[li]["z"]).max() / scale < 1e-4, f"layer {li} {spec.name} pre-BN output differs"
+    assert np.abs(probs.cpu().numpy() - ref).max() < PROB_TOL
+    ref_am = ref.argmax(-1)
+    # identical argmax except at numerical ties
+    diff = am.cpu().numpy() != ref_am
+    if diff.any():
+        srt = np.sort(ref, -1)
+        assert (srt[..., -1] - srt[..., -2])[diff].max() < 1e-4
+    # float32 input path gives the same result as the u8 path
+    xf = torch.from_numpy(on.preprocess_u8(images, np.float32)).cuda()
+    probs_f, _ = eng.forward(xf, training=False)
+    assert torch.equal(probs_f, probs)
+
+
+@pytest.mark.parametrize("macro", [True, False])
+@pytest.mark.parametrize("case", CASES)
+def test_training_step_matches_oracle(case, macro):
+    B, H, W, C, sn, P, L, ic = case
+    cfg, eng, p64, s64 = make(B, H, W, C, sn, P, L, ic, training=True)
+    images, labels = data(B, H, W, C, ic)
+    x = torch.from_numpy(images).cuda()
+    lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+    eng.set_dropout_step(3)
+    mask = eng.dropout_mask(B).cpu().numpy().astype(np.float64)
+    assert 0.3 < mask.mean() < 0.7
+    probs, _ = eng.forward(x, training=True, labels=lab)
+    loss4 = eng.loss_dice().cpu().numpy()
+    eng.backward(lab, macro=macro, loss_scale=0.5)
+    torch.cuda.synchronize()
+
+    xin = on.preprocess_u8(images, np.float64)
+    ref, cache = on.forward(cfg, p64, s64, xin, training=True, dropout_mask=mask)
+    plan = on.build_plan(cfg)
+    for li, spec in enumerate(plan[:-1]):
+        z = eng.debug_activation(li, 0)[:B].cpu().numpy()
+        scale = max(1.0, np.abs(cache[li]["z"]).max())
+        assert np.abs(z - cache[li]["z"]).max() / scale < 1e-4, f"layer {li} {spec.name} pre-BN output differs"
+    assert np.abs(probs.cpu().numpy() - ref).max() < PROB_TOL
+
+    y = on.one_hot(labels, C, np.float64)
+    assert abs(loss4[0] - on.dice_loss_macro(y, ref)) < 1e-5
+    assert abs(loss4[1] - on.dice_loss_micro(y, ref)) < 1e-5
+    assert abs(loss4[2] - on.dice_coef_macro(y, ref)) < DICE_TOL
+    assert abs(loss4[3] - on.dice_coef_micro(y, ref)) < DICE_TOL
+
+    loss, grads = on.backward(cfg, p64, cache, labels, macro=macro, loss_scale=0.5)
+    # layer-wise dz from the last block backwards
+    for li in range(len(plan) - 2, -1, -1):
+        dz = eng.debug_activation(li, 1)[:B].cpu().numpy()
+        ref_dz = cache[li]["dz"]
+        scale = np.abs(ref_dz).max()
+        assert np.abs(dz - ref_dz).max() / scale < 5e-4, f"layer {li} {plan[li].name} dz differs"
+    g = eng.grads.cpu().numpy()
+    for L_, gr in zip(eng.layers, grads):
+        n = L_["kh"] * L_["kw"] * L_["cin"] * L_["cout"]; c = L_["cout"]
+        pieces = [("kernel", L_["kernel_off"], n), ("bias", L_["bias_off"], c)]
+        if L_["has_bn"]:
+            pieces += [("gamma", L_["gamma_off"], c), ("beta", L_["beta_off"], c)]
+        kscale = np.abs(gr["kernel"]).max()
+        for key, off, cnt in pieces:
+            refv = gr[key].ravel()
+            # a conv bias ahead of a BN has an analytically zero gradient: judge it on the kernel's scale
+            scale = max(np.abs(refv).max(), kscale if key == "bias" else 0.0, 1e-12)
+            err = np.abs(g[off:off + cnt] - refv).max() / scale
+            assert err < GRAD_RTOL, f"{L_['name']}.{key}: rel err {err}"
+
+    # moving statistics (Bessel-corrected variance, momentum 0.99)
+    new_state = on.flatten_state(on.updated_moving_stats(cfg, s64, cache))
+    assert np.abs(eng.state.cpu().numpy() - new_state).max() < 1e-5
+
+
+def test_adam_and_sgd_steps_match_keras_formulas():
+    B, H, W, C = 2, 32, 64, 3
+    cfg, eng, p64, s64 = make(B, H, W, C, 8, 2)
+    images, labels = data(B, H, W, C)
+    x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+    theta = eng.params.cpu().numpy().astype(np.float64)
+    m = np.zeros_like(theta); v = np.zeros_like(theta)
+    for t in (1, 2, 3):
+        eng.forward(x, training=True, labels=lab, want_probs=False)
+        eng.loss_dice(); eng.backward(lab)
+        g = eng.grads.cpu().numpy().astype(np.float64)
+        eng.adam_step(lr=1e-3)
+        theta, m, v = on.adam_step(theta, g, m, v, t)
+        assert np.abs(eng.params.cpu().numpy() - theta).max() < 2e-6
+    mom = np.zeros_like(theta)
+    for _ in range(2):
+        eng.forward(x, training=True, labels=lab, want_probs=False)
+        eng.loss_dice(); eng.backward(lab)
+        g = eng.grads.cpu().numpy().astype(np.float64)
+        theta = eng.params.cpu().numpy().astype(np.float64)
+        eng.sgd_step(lr=0.05, momentum=0.9)
+        theta, mom = on.sgd_step(theta, g, mom, lr=0.05, momentum=0.9)
+        assert np.abs(eng.params.cpu().numpy() - theta).max() < 2e-6
+
+
+def test_training_reduces_loss_and_eval_mode_uses_moving_stats():
+    B, H, W, C = 4, 32, 64, 3
+    cfg, eng, _, _ = make(B, H, W, C, 8, 2, seed=1)
+    images, labels = data(B, H, W, C, seed=2)
+    x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+    losses = []
+    for it in range(60):
+        eng.set_dropout_step(it)
+        eng.forward(x, training=True, labels=lab, want_probs=False)
+        losses.append(eng.loss_dice()); eng.backward(lab); eng.adam_step(lr=5e-3)
+    losses = torch.stack(losses).cpu().numpy()
+    assert losses[-1, 0] < 0.6 * losses[0, 0], losses[:, 0]
+    assert np.isfinite(eng.params.cpu().numpy()).all()
+
+
+def test_partial_batch_and_graph_replay():
+    B, H, W, C = 4, 32, 64, 3
+    cfg, eng, p64, s64 = make(B, H, W, C, 8, 2, training=False, max_batch=B)
+    images, _ = data(B, H, W, C)
+    x = torch.from_numpy(images).cuda()
+    full, _ = eng.forward(x, training=False)
+    part, _ = eng.forward(x[:3].contiguous(), training=False)
+    assert torch.equal(part, full[:3])  # per-scan results independent of batch composition in inference
+    xb = x.clone()
+    gp, gam = eng.graph_capture(xb, want_probs=True, want_argmax=True)
+    eng.graph_launch(); torch.cuda.synchronize()
+    assert torch.equal(gp, full) and torch.equal(gam.long(), full.argmax(-1))
+    xb.copy_(torch.flip(x, dims=[0])); eng.graph_launch(); torch.cuda.synchronize()
+    assert torch.equal(gp, torch.flip(full, dims=[0]))
+
+
+def test_api_errors_are_loud():
+    from oct_image_segmentation_models_amd._hip import OctError
+    cfg, eng, _, _ = make(2, 32, 64, 3, 8, 2, training=False)
+    x = torch.zeros((2, 32, 64, 1), dtype=torch.uint8, device="cuda")
+    with pytest.raises(OctError):
+        eng.forward(x, training=True)               # no training workspaces
+    with pytest.raises(OctError):
+        eng.forward(torch.zeros((3, 32, 64, 1), dtype=torch.uint8, device="cuda"))  # B > max_batch
+    with pytest.raises(OctError):
+        eng.forward(x.cpu())
+    eng.forward(x)
+    with pytest.raises(OctError):
+        eng.loss_dice()                              # forward had no labels
+
+
+def test_full_size_properties_config2():
+    """BASELINE config[1] shape (256x512, P=4, C=3): size-independent properties at full size --
+    probabilities sum to 1, batch-composition independence in inference, per-scan linearity of the
+    macro-Dice batch loss (mean of single-scan losses), gradient buffer finite and non-trivial."""
+    B, H, W, C = 4, 256, 512, 3
+    cfg, eng, _, _ = make(B, H, W, C, 8, 4, training=True)
+    images, labels = data(B, H, W, C, seed=9)
+    x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+    probs, am = eng.forward(x, training=False, labels=lab, want_argmax=True)
+    l_all = eng.loss_dice().cpu().numpy()
+    assert torch.allclose(probs.sum(-1), torch.ones_like(probs[..., 0]), atol=1e-5)
+    assert torch.equal(am.long(), probs.argmax(-1))
+    singles = []
+    for i in range(B):
+        pi, _ = eng.forward(x[i:i + 1].contiguous(), training=False, labels=lab[i:i + 1].contiguous())
+        assert torch.equal(pi[0], probs[i])
+        singles.append(eng.loss_dice().cpu().numpy())
+    assert abs(np.mean([s[0] for s in singles]) - l_all[0]) < 1e-6
+    eng.forward(x, training=True, labels=lab, want_probs=False)
+    eng.loss_dice(); eng.backward(lab)
+    g = eng.grads.cpu().numpy()
+    assert np.isfinite(g).all() and np.abs(g).max() > 1e-6
