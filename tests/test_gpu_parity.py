@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import unet_numpy as on
+from tests.helpers import dropout_keep_mask, relu_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -43,8 +44,13 @@ CASES = [
     (2, 32, 64, 3, 8, 2, 2, 1),
     (3, 16, 32, 4, 4, 2, 2, 1),
     (1, 48, 80, 3, 8, 3, 1, 3),     # ragged tiles (48x80 not multiples of the 8x32 thread tile), 3 input channels
-    (2, 64, 64, 2, 16, 1, 3, 1),
+    (1, 32, 64, 2, 16, 1, 3, 1),
 ]
+# Data seeds (found offline with the oracle alone) for which every BN pre-activation of the training
+# forward stays > 2e-5 away from the ReLU kink: fp32-vs-fp64 rounding then cannot flip a ReLU mask, so the
+# gradient comparison can use tight tolerances.  The margin is re-asserted inside the test.
+MARGIN_SEED = {CASES[0]: 97, CASES[1]: 13, CASES[2]: 28, CASES[3]: 75}
+DROP_STEP = 3
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -78,11 +84,14 @@ def test_inference_forward_matches_oracle(case):
 def test_training_step_matches_oracle(case, macro):
     B, H, W, C, sn, P, L, ic = case
     cfg, eng, p64, s64 = make(B, H, W, C, sn, P, L, ic, training=True)
-    images, labels = data(B, H, W, C, ic)
+    images, labels = data(B, H, W, C, ic, seed=MARGIN_SEED[case])
     x = torch.from_numpy(images).cuda()
     lab = torch.from_numpy(labels[..., 0].copy()).cuda()
-    eng.set_dropout_step(3)
-    mask = eng.dropout_mask(B).cpu().numpy().astype(np.float64)
+    eng.set_dropout_step(DROP_STEP)
+    mask = eng.dropout_mask(B).cpu().numpy()
+    # the device dropout stream is the documented counter hash (seed = engine seed, step, element index)
+    assert np.array_equal(mask, dropout_keep_mask(100, DROP_STEP, mask.shape).astype(np.uint8))
+    mask = mask.astype(np.float64)
     assert 0.3 < mask.mean() < 0.7
     probs, _ = eng.forward(x, training=True, labels=lab)
     loss4 = eng.loss_dice().cpu().numpy()
@@ -91,6 +100,7 @@ def test_training_step_matches_oracle(case, macro):
 
     xin = on.preprocess_u8(images, np.float64)
     ref, cache = on.forward(cfg, p64, s64, xin, training=True, dropout_mask=mask)
+    assert relu_margin(cfg, p64, cache) > 2e-5, "test input lost its ReLU margin; re-run the seed search"
     plan = on.build_plan(cfg)
     for li, spec in enumerate(plan[:-1]):
         z = eng.debug_activation(li, 0)[:B].cpu().numpy()
