@@ -117,6 +117,19 @@ int oct_unet_graph_capture(oct_unet* h, const void* x_dev, int x_is_u8, int B, c
                            oct_stream_t stream);
 int oct_unet_graph_launch(oct_unet* h, oct_stream_t stream);
 
+/* ---- per-launch profiler: HIP events recorded around every kernel launch, on the launch stream ----
+ * begin() arms it; every forward/backward call of this handle made on the calling thread is then recorded;
+ * end() synchronises the device and returns one entry per (kernel instantiation, layer) with the summed
+ * duration and the ALGORITHMIC flops/bytes of those launches (cost model). */
+typedef struct oct_profile_entry {
+    char kernel[48];
+    char layer[32];
+    int launches;
+    double total_ms, flops, bytes;
+} oct_profile_entry;
+int oct_unet_profile_begin(oct_unet* h);
+int oct_unet_profile_end(oct_unet* h, oct_profile_entry* out, int max_entries, int* n_out);
+
 /* ---- introspection for tests: device pointer of a layer's saved pre-BN output / gradient ---- */
 const float* oct_unet_debug_activation(oct_unet* h, int layer, int which /*0=z,1=g*/);
 

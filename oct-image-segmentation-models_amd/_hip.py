@@ -37,6 +37,11 @@ class LayerInfo(C.Structure):
     ]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("kernel", C.c_char * 48), ("layer", C.c_char * 32), ("launches", C.c_int),
+                ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 class UNetIO(C.Structure):
     _fields_ = [("probs", C.c_void_p), ("argmax", C.c_void_p), ("labels", C.c_void_p)]
 
@@ -64,6 +69,8 @@ SYMBOLS = [
     ("oct_unet_dropout_mask", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("oct_unet_graph_capture", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(UNetIO), C.c_void_p]),
     ("oct_unet_graph_launch", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("oct_unet_profile_begin", C.c_int, [C.c_void_p]),
+    ("oct_unet_profile_end", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _P(C.c_int)]),
     ("oct_unet_debug_activation", C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
     ("oct_last_error", C.c_char_p, []),
     ("oct_version", C.c_char_p, []),

@@ -26,6 +26,31 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (e__ != hipSuccess) return fail(-5, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
+// ---- per-launch HIP-event profiler (off by default; bench.py turns it on for a few untimed steps) ---------
+struct ProfRec { std::string kernel, layer; double flops, bytes; hipEvent_t e0, e1; };
+struct Profiler {
+    bool on = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+};
+thread_local Profiler* t_prof = nullptr;
+
+// RAII: records an event pair around the launch(es) issued in its scope, on the launch stream itself
+struct ProfScope {
+    Profiler* p; hipStream_t s; size_t idx;
+    ProfScope(hipStream_t st, const char* kernel, const char* layer, double flops, double bytes) : p(t_prof), s(st), idx(0) {
+        if (!p || !p->on) { p = nullptr; return; }
+        ProfRec r{kernel, layer, flops, bytes, p->get(), p->get()};
+        (void)hipEventRecord(r.e0, s);
+        idx = p->recs.size(); p->recs.push_back(r);
+    }
+    ~ProfScope() { if (p) (void)hipEventRecord(p->recs[idx].e1, s); }
+};
+
 enum Src { SRC_INPUT, SRC_PREV, SRC_POOL, SRC_UP, SRC_CONCAT, SRC_HEAD };
 
 struct Layer {
@@ -135,10 +160,11 @@ struct oct_unet {
     float* dw_part = nullptr;
     float* dice_part = nullptr; double* dice_bc = nullptr; float* loss4 = nullptr;
     float* dlogits = nullptr;
-    unsigned long long drop_step = 0;
+    unsigned long long drop_step = 0; int drop_advance = 0;
     int last_B = 0; int last_training = 0; int have_dice = 0; int dice_final = 0;
     const void* last_x = nullptr; int last_u8 = 0;   // input of the last forward (first layer's dW re-reads it)
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    Profiler prof;
 };
 
 namespace {
@@ -192,9 +218,11 @@ DropCfg make_drop(const oct_unet* h) {
 // forward launches
 // ---------------------------------------------------------------------------------------------------------------
 template <int KH, int FLAGS>
-int launch_conv_fwd_co(const ConvFwdArgs& a, int B, hipStream_t s) {
+int launch_conv_fwd_co(const ConvFwdArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes) {
     const int co_t = chunk_of(a.Cout);
     dim3 grid(a.tiles, a.Cout / co_t, B), block(kBlock);
+    char nm[48]; snprintf(nm, sizeof nm, "conv_fwd_k<%d,%d,%d>", KH, co_t, FLAGS);
+    ProfScope ps(s, nm, layer, flops, bytes);
     switch (co_t) {
         case 16: conv_fwd_k<KH, 16, FLAGS><<<grid, block, 0, s>>>(a); break;
         case 8: conv_fwd_k<KH, 8, FLAGS><<<grid, block, 0, s>>>(a); break;
@@ -223,6 +251,15 @@ SrcDesc src_of(const oct_unet* h, int li, const void* x_in, int x_is_u8) {
     return d;
 }
 
+// algorithmic bytes of a conv's logical input, read once: low-res tensor for an up-conv, both
+// halves of a concat, the pooled tensor after a pool, 1 B/px for a u8 image
+double in_bytes(const Layer& l, int B, int x_is_u8) {
+    const double px = (double)B * l.H * l.W;
+    if (l.src == SRC_INPUT) return px * l.cin * (x_is_u8 ? 1 : 4);
+    if (l.src == SRC_UP) return px / 4 * l.cin * 4;
+    return px * l.cin * 4;
+}
+
 int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int training, hipStream_t s) {
     Layer& l = h->plan.L[li];
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
@@ -234,17 +271,20 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
     a.tiles_x = cdiv(l.W, kTileX); a.tiles = tiles_of(l.H, l.W);
     a.drop = make_drop(h);
     const bool drop = training && l.drop_in;
+    const double px = (double)B * l.H * l.W, fl = 2.0 * l.kh * l.kw * l.cin * l.cout * px;
+    const double by = in_bytes(l, B, x_is_u8) + px * l.cout * 4;   // logical input once + output once
     int rc;
     switch (l.src) {
-        case SRC_INPUT: rc = x_is_u8 ? launch_conv_fwd_co<3, F_U8>(a, B, s) : launch_conv_fwd_co<3, 0>(a, B, s); break;
-        case SRC_POOL: rc = launch_conv_fwd_co<3, 0>(a, B, s); break;
-        case SRC_PREV: rc = launch_conv_fwd_co<3, F_AFF>(a, B, s); break;
-        case SRC_CONCAT: rc = launch_conv_fwd_co<3, F_AFF | F_TWO>(a, B, s); break;
-        case SRC_UP: rc = drop ? launch_conv_fwd_co<2, F_AFF | F_UP | F_DROP>(a, B, s) : launch_conv_fwd_co<2, F_AFF | F_UP>(a, B, s); break;
+        case SRC_INPUT: rc = x_is_u8 ? launch_conv_fwd_co<3, F_U8>(a, B, s, l.name, fl, by) : launch_conv_fwd_co<3, 0>(a, B, s, l.name, fl, by); break;
+        case SRC_POOL: rc = launch_conv_fwd_co<3, 0>(a, B, s, l.name, fl, by); break;
+        case SRC_PREV: rc = launch_conv_fwd_co<3, F_AFF>(a, B, s, l.name, fl, by); break;
+        case SRC_CONCAT: rc = launch_conv_fwd_co<3, F_AFF | F_TWO>(a, B, s, l.name, fl, by); break;
+        case SRC_UP: rc = drop ? launch_conv_fwd_co<2, F_AFF | F_UP | F_DROP>(a, B, s, l.name, fl, by) : launch_conv_fwd_co<2, F_AFF | F_UP>(a, B, s, l.name, fl, by); break;
         default: return fail(-3, "conv_forward: bad src");
     }
     if (rc) return rc;
     if (l.has_bn && training) {
+        ProfScope ps(s, "bn_fwd_finalize_k", l.name, 0, (double)B * a.tiles * 2 * l.cout * 4);
         BnFinArgs f{};
         f.part = h->stat_part; f.nblk = B * a.tiles; f.C = l.cout; f.count = (double)B * l.H * l.W;
         f.gamma = h->params + l.gamma_off; f.beta = h->params + l.beta_off; f.bn = l.bn;
@@ -259,6 +299,9 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
 template <int C>
 int launch_head_fwd(const HeadFwdArgs& a, int cin, int B, hipStream_t s) {
     dim3 grid(a.nblk, B), block(kBlock);
+    const double px = (double)B * a.HW;
+    char nm[48]; snprintf(nm, sizeof nm, "head_fwd_k<%d,%d>", C, cin);
+    ProfScope ps(s, nm, "head", 2.0 * cin * C * px, px * (cin * 4 + (a.probs ? C * 4 : 0) + (a.argmax ? 1 : 0) + (a.labels ? 1 : 0)));
     switch (cin) {
         case 4: head_fwd_k<C, 4><<<grid, block, 0, s>>>(a); break;
         case 8: head_fwd_k<C, 8><<<grid, block, 0, s>>>(a); break;
@@ -272,6 +315,9 @@ int launch_head_fwd(const HeadFwdArgs& a, int cin, int B, hipStream_t s) {
 template <int C>
 int launch_head_bwd(const HeadBwdArgs& a, int cin, int B, hipStream_t s) {
     dim3 grid(a.nblk, B), block(kBlock);
+    const double px = (double)B * a.HW;
+    char nm[48]; snprintf(nm, sizeof nm, "head_bwd_k<%d,%d>", C, cin);
+    ProfScope ps(s, nm, "head", 4.0 * cin * C * px, px * (cin * 4 * 2 + C * 4 + 1));
     switch (cin) {
         case 4: head_bwd_k<C, 4><<<grid, block, 0, s>>>(a); break;
         case 8: head_bwd_k<C, 8><<<grid, block, 0, s>>>(a); break;
@@ -302,6 +348,7 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
     Plan& pl = h->plan;
     const int nl = (int)pl.L.size();
     if (!training) {  // (a, b) from moving statistics
+        ProfScope ps(s, "bn_infer_coeffs_k", "all", 0, (double)pl.n_state * 4 * 3);
         for (auto& l : pl.L)
             if (l.has_bn) {
                 bn_infer_coeffs_k<<<cdiv(l.cout, 64), 64, 0, s>>>(h->params + l.gamma_off, h->params + l.beta_off,
@@ -315,6 +362,7 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
             const Layer& p = pl.L[li - 1];
             const size_t n = (size_t)B * (p.H / 2) * (p.W / 2) * (p.cout / 4);
             const int grid = (int)std::min<size_t>((n + kBlock - 1) / kBlock, 8192);
+            ProfScope ps(s, "pool_fwd_k", p.name, 0, (double)n * 16 * 5);   // read 4 px, write 1
             pool_fwd_k<<<grid, kBlock, 0, s>>>(p.z, p.bn, h->pooled[l.level - 1], B, p.H, p.W, p.cout);
             HIP_OK(hipGetLastError());
         }
@@ -337,8 +385,10 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
 // backward launches
 // ---------------------------------------------------------------------------------------------------------------
 template <int KH>
-int launch_dw(const ConvBwdWArgs& a, int ci_t, int co_t, hipStream_t s) {
+int launch_dw(const ConvBwdWArgs& a, int ci_t, int co_t, hipStream_t s, const char* layer, double flops, double bytes) {
     dim3 grid(a.npb, cdiv(a.Cin, ci_t), cdiv(a.Cout, co_t)), block(kBlock);
+    char nm[48]; snprintf(nm, sizeof nm, "conv_bwd_w_k<%d,%d,%d>", KH, ci_t, co_t);
+    ProfScope ps(s, nm, layer, flops, bytes);
 #define DW_CASE(CI, CO) if (ci_t == CI && co_t == CO) { conv_bwd_w_k<KH, CI, CO><<<grid, block, 0, s>>>(a); HIP_OK(hipGetLastError()); return 0; }
     DW_CASE(1, 4) DW_CASE(1, 8) DW_CASE(1, 16)
     DW_CASE(4, 4) DW_CASE(4, 8) DW_CASE(4, 16)
@@ -360,14 +410,17 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const fl
     const int ci_t = dw_ci_t(l), co_t = dw_co_t(l);
     a.npb = dw_npb(l, B, ci_t, co_t);
     a.drop = make_drop(h);
+    const double px = (double)B * l.H * l.W, fl = 2.0 * l.kh * l.kw * l.cin * l.cout * px;
+    const double by = in_bytes(l, B, x_is_u8) + px * l.cout * 4;   // conv input once + dz once
     int rc;
     switch (l.kh) {
-        case 1: rc = launch_dw<1>(a, ci_t, co_t, s); break;
-        case 2: rc = launch_dw<2>(a, ci_t, co_t, s); break;
-        default: rc = launch_dw<3>(a, ci_t, co_t, s); break;
+        case 1: rc = launch_dw<1>(a, ci_t, co_t, s, l.name, fl, by); break;
+        case 2: rc = launch_dw<2>(a, ci_t, co_t, s, l.name, fl, by); break;
+        default: rc = launch_dw<3>(a, ci_t, co_t, s, l.name, fl, by); break;
     }
     if (rc) return rc;
     const size_t wsize = (size_t)l.kh * l.kw * l.cin * l.cout, stride = wsize + l.cout;
+    ProfScope ps(s, "reduce_partials_k", l.name, 0, (double)a.npb * stride * 4);
     reduce_partials_k<<<(int)((stride + kBlock - 1) / kBlock), kBlock, 0, s>>>(h->dw_part, a.npb, stride, wsize,
                                                                               h->grads + l.w_off, h->grads + l.b_off);
     HIP_OK(hipGetLastError());
@@ -375,9 +428,13 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const fl
 }
 
 template <int KH, bool UP, int EPI>
-int launch_dx(const ConvBwdDataArgs& a, int B, hipStream_t s) {
+int launch_dx(const ConvBwdDataArgs& a, int B, hipStream_t s, const char* layer) {
     const int ci_t = std::min(chunk_of(a.Cg), 8);
     dim3 grid(a.tiles, a.Cg / ci_t, B), block(kBlock);
+    const double px = (double)B * a.H * a.W, pxg = (double)B * a.Hg * a.Wg;
+    char nm[48]; snprintf(nm, sizeof nm, "conv_bwd_data_k<%d,%d,%d,%d>", KH, ci_t, (int)UP, EPI);
+    // dz once + gradient written once (+ producer's z once for the ReLU mask / BN-backward statistics)
+    ProfScope ps(s, nm, layer, 2.0 * KH * KH * a.Cg * a.Cout * px, px * a.Cout * 4 + pxg * a.Cg * 4 * (EPI == E_RAW ? 1 : 2));
     if (ci_t == 8) conv_bwd_data_k<KH, 8, UP, EPI><<<grid, block, 0, s>>>(a);
     else conv_bwd_data_k<KH, 4, UP, EPI><<<grid, block, 0, s>>>(a);
     HIP_OK(hipGetLastError());
@@ -390,9 +447,11 @@ int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s) {
     BnBwdFinArgs f{};
     f.part = h->stat_part; f.nblk = nblk; f.C = l.cout; f.count = (double)B * l.H * l.W;
     f.bn = l.bn; f.dgamma = h->grads + l.gamma_off; f.dbeta = h->grads + l.beta_off;
-    bn_bwd_finalize_k<<<l.cout, kBlock, 0, s>>>(f);
+    { ProfScope ps(s, "bn_bwd_finalize_k", l.name, 0, (double)nblk * 2 * l.cout * 4);
+      bn_bwd_finalize_k<<<l.cout, kBlock, 0, s>>>(f); }
     const size_t n4 = (size_t)B * l.H * l.W * l.cout / 4;
     const int grid = (int)std::min<size_t>((n4 + kBlock - 1) / kBlock, 8192);
+    ProfScope ps(s, "bn_bwd_apply_k", l.name, 0, (double)n4 * 16 * 3);
     bn_bwd_apply_k<<<grid, kBlock, 0, s>>>(l.g, l.z, l.bn, h->params + l.gamma_off, n4, l.cout);
     HIP_OK(hipGetLastError());
     return 0;
@@ -433,20 +492,21 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             case SRC_PREV: {
                 Layer& p = pl.L[li - 1];
                 set_out(p.g, p.cout, 0, l.H, l.W, &p);
-                rc = launch_dx<3, false, E_MASK>(a, B, s);
+                rc = launch_dx<3, false, E_MASK>(a, B, s, l.name);
                 pending_nblk = B * a.tiles;
                 break;
             }
             case SRC_POOL: {  // gradient wrt the pooled tensor (raw), then route through the pool into block li-1
                 Layer& p = pl.L[li - 1];
                 set_out(h->gpooled[l.level - 1], l.cin, 0, l.H, l.W, nullptr);
-                rc = launch_dx<3, false, E_RAW>(a, B, s);
+                rc = launch_dx<3, false, E_RAW>(a, B, s, l.name);
                 if (rc) return rc;
                 PoolBwdArgs pb{};
                 pb.gp = h->gpooled[l.level - 1]; pb.z = p.z; pb.bn = p.bn; pb.g = p.g; pb.part = h->stat_part;
                 pb.H = p.H; pb.W = p.W; pb.C = p.cout; pb.tiles_x = cdiv(p.W / 2, kTileX); pb.tiles = tiles_of(p.H / 2, p.W / 2);
                 const int c_t = std::min(chunk_of(p.cout), 8);
                 dim3 grid(pb.tiles, p.cout / c_t, B);
+                ProfScope ps(s, c_t == 8 ? "pool_bwd_k<8>" : "pool_bwd_k<4>", p.name, 0, (double)B * p.H * p.W * p.cout * 4 * 3.25);
                 if (c_t == 8) pool_bwd_k<8><<<grid, kBlock, 0, s>>>(pb); else pool_bwd_k<4><<<grid, kBlock, 0, s>>>(pb);
                 HIP_OK(hipGetLastError());
                 pending_nblk = B * pb.tiles;
@@ -455,7 +515,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             case SRC_UP: {
                 Layer& p = pl.L[li - 1];
                 set_out(p.g, p.cout, 0, l.H / 2, l.W / 2, &p);
-                rc = l.drop_in ? launch_dx<2, true, E_MASK_DROP>(a, B, s) : launch_dx<2, true, E_MASK>(a, B, s);
+                rc = l.drop_in ? launch_dx<2, true, E_MASK_DROP>(a, B, s, l.name) : launch_dx<2, true, E_MASK>(a, B, s, l.name);
                 pending_nblk = B * a.tiles;
                 break;
             }
@@ -463,11 +523,11 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
                 Layer& p = pl.L[li - 1]; Layer& k = pl.L[l.skip_from];
                 // skip half first (raw, merged later by pool_bwd of that encoder level) ...
                 set_out(k.g, k.cout, p.cout, l.H, l.W, nullptr);
-                rc = launch_dx<3, false, E_RAW>(a, B, s);
+                rc = launch_dx<3, false, E_RAW>(a, B, s, l.name);
                 if (rc) return rc;
                 // ... then the up-path half, whose statistics must be the ones pending for block li-1
                 set_out(p.g, p.cout, 0, l.H, l.W, &p);
-                rc = launch_dx<3, false, E_MASK>(a, B, s);
+                rc = launch_dx<3, false, E_MASK>(a, B, s, l.name);
                 pending_nblk = B * a.tiles;
                 break;
             }
@@ -557,6 +617,11 @@ int oct_unet_forward(oct_unet* h, const void* x, int x_is_u8, int B, int trainin
     if (!h || !x) return fail(-1, "null handle or input");
     if (B < 1 || B > h->cfg.max_batch) return fail(-1, "B out of range (1..max_batch)");
     if (training && !h->cfg.training) return fail(-1, "handle was created without training workspaces");
+    if (training) {  // every training forward draws a fresh dropout mask; backward replays the same one
+        if (h->drop_advance) ++h->drop_step;
+        h->drop_advance = 1;
+    }
+    t_prof = &h->prof;
     const int rc = forward_impl(h, x, x_is_u8, B, training, io, (hipStream_t)stream);
     if (rc) return rc;
     h->last_x = x; h->last_u8 = x_is_u8; h->dice_final = 0;
@@ -579,6 +644,7 @@ int oct_unet_backward(oct_unet* h, const unsigned char* labels, int macro, float
     if (!h || !labels) return fail(-1, "null handle or labels");
     if (!h->last_training || !h->have_dice || !h->dice_final)
         return fail(-1, "backward needs a training forward with io.labels followed by oct_unet_loss_dice");
+    t_prof = &h->prof;
     return backward_impl(h, h->last_x, h->last_u8, labels, macro, loss_scale, (hipStream_t)stream);
 }
 
@@ -602,7 +668,7 @@ int oct_sgd_step(float* p, const float* g, float* mom, size_t n, float lr, float
 
 int oct_unet_set_dropout_step(oct_unet* h, unsigned long long step) {
     if (!h) return fail(-1, "null handle");
-    h->drop_step = step;
+    h->drop_step = step; h->drop_advance = 0;
     return 0;
 }
 
@@ -622,6 +688,7 @@ int oct_unet_graph_capture(oct_unet* h, const void* x, int x_is_u8, int B, const
     if (!s) return fail(-1, "graph capture needs a non-default stream");
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    t_prof = nullptr;  // no event records inside a capture
     HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = forward_impl(h, x, x_is_u8, B, 0, io, s);
     hipError_t e = hipStreamEndCapture(s, &h->graph);
@@ -634,6 +701,36 @@ int oct_unet_graph_capture(oct_unet* h, const void* x, int x_is_u8, int B, const
 int oct_unet_graph_launch(oct_unet* h, oct_stream_t stream) {
     if (!h || !h->graph_exec) return fail(-1, "no captured graph");
     HIP_OK(hipGraphLaunch(h->graph_exec, (hipStream_t)stream));
+    return 0;
+}
+
+int oct_unet_profile_begin(oct_unet* h) {
+    if (!h) return fail(-1, "null handle");
+    for (auto& r : h->prof.recs) { h->prof.pool.push_back(r.e0); h->prof.pool.push_back(r.e1); }
+    h->prof.recs.clear();
+    h->prof.on = true;
+    return 0;
+}
+
+int oct_unet_profile_end(oct_unet* h, oct_profile_entry* out, int max_entries, int* n_out) {
+    if (!h || !n_out) return fail(-1, "null argument");
+    h->prof.on = false;
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<oct_profile_entry> agg;
+    for (auto& r : h->prof.recs) {
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        oct_profile_entry* e = nullptr;
+        for (auto& a : agg) if (r.kernel == a.kernel && r.layer == a.layer) { e = &a; break; }
+        if (!e) {
+            oct_profile_entry n{}; snprintf(n.kernel, sizeof n.kernel, "%s", r.kernel.c_str());
+            snprintf(n.layer, sizeof n.layer, "%s", r.layer.c_str());
+            agg.push_back(n); e = &agg.back();
+        }
+        e->launches += 1; e->total_ms += ms; e->flops += r.flops; e->bytes += r.bytes;
+    }
+    *n_out = (int)agg.size();
+    for (int i = 0; i < (int)agg.size() && i < max_entries && out; ++i) out[i] = agg[i];
     return 0;
 }
 

@@ -192,6 +192,19 @@ class UNetEngine:
             _hip.check(_hip.lib().oct_sgd_step(self.params.data_ptr(), self.grads.data_ptr(), mom, self.n_params, lr,
                                                momentum, self._stream()), "oct_sgd_step")
 
+    # ---- per-launch profiler ---------------------------------------------------------------------
+    def profile_begin(self):
+        _hip.check(_hip.lib().oct_unet_profile_begin(self._h), "oct_unet_profile_begin")
+
+    def profile_end(self) -> List[dict]:
+        """One dict per (kernel instantiation, layer): launches, total_ms, algorithmic flops and bytes."""
+        n = C.c_int(0)
+        buf = (_hip.ProfileEntry * 1024)()
+        with torch.cuda.device(self.device):
+            _hip.check(_hip.lib().oct_unet_profile_end(self._h, buf, 1024, C.byref(n)), "oct_unet_profile_end")
+        return [dict(kernel=buf[i].kernel.decode(), layer=buf[i].layer.decode(), launches=buf[i].launches,
+                     total_ms=buf[i].total_ms, flops=buf[i].flops, bytes=buf[i].bytes) for i in range(min(n.value, 1024))]
+
     # ---- dropout replay (tests) -------------------------------------------------------------------
     def set_dropout_step(self, step: int):
         _hip.check(_hip.lib().oct_unet_set_dropout_step(self._h, step), "oct_unet_set_dropout_step")
