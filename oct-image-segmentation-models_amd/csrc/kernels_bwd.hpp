@@ -379,14 +379,22 @@ __global__ __launch_bounds__(kBlock) void conv_bwd_w_k(const ConvBwdWArgs A) {
     }
 }
 
-// second stage: grads[j] = sum over pixel blocks of part[pb][j]
+// second stage: grads[j] = sum over pixel blocks of part[pb][j].  Block = 64 consecutive j x 4 slices of pb;
+// fixed summation order (deterministic), double accumulation.
 __global__ __launch_bounds__(kBlock) void reduce_partials_k(const float* __restrict__ part, int npb, size_t stride,
                                                            size_t wsize, float* __restrict__ dw, float* __restrict__ db) {
-    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= stride) return;
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const size_t j = (size_t)blockIdx.x * 64 + lane;
     double s = 0;
-    for (int p = 0; p < npb; ++p) s += part[(size_t)p * stride + j];
-    if (j < wsize) dw[j] = (float)s; else db[j - wsize] = (float)s;
+    if (j < stride)
+        for (int p = q; p < npb; p += 4) s += part[(size_t)p * stride + j];
+    sh[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && j < stride) {
+        const double t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        if (j < wsize) dw[j] = (float)t; else db[j - wsize] = (float)t;
+    }
 }
 
 // ---- optimizers (Keras formulations) ----------------------------------------------------

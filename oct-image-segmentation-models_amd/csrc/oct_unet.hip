@@ -142,7 +142,7 @@ inline int chunk_of(int c) { return c % 16 == 0 ? 16 : (c % 8 == 0 ? 8 : 4); }  
 int dw_npb(const Layer& l, int B, int ci_t, int co_t) {
     const int chunks = cdiv(l.cin, ci_t) * cdiv(l.cout, co_t);
     const int total = B * tiles_of(l.H, l.W);
-    int npb = cdiv(2048, chunks);
+    int npb = cdiv(1024, chunks);
     if (npb > total) npb = total;
     return npb < 1 ? 1 : npb;
 }
@@ -421,7 +421,7 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const fl
     if (rc) return rc;
     const size_t wsize = (size_t)l.kh * l.kw * l.cin * l.cout, stride = wsize + l.cout;
     ProfScope ps(s, "reduce_partials_k", l.name, 0, (double)a.npb * stride * 4);
-    reduce_partials_k<<<(int)((stride + kBlock - 1) / kBlock), kBlock, 0, s>>>(h->dw_part, a.npb, stride, wsize,
+    reduce_partials_k<<<(int)((stride + 63) / 64), kBlock, 0, s>>>(h->dw_part, a.npb, stride, wsize,
                                                                               h->grads + l.w_off, h->grads + l.b_off);
     HIP_OK(hipGetLastError());
     return 0;
