@@ -1,0 +1,119 @@
+"""Batch generator with the reference's input contract
+(oct_image_segmentation_models/common/data_generator.py:10-416), re-stated for augmentation mode "none":
+
+* ``X = float32(images / 255)`` of shape (B,H,W,C) -- the reference computes ``u8/255*255/255``
+  (data_generator.py:76,239 + models/unet.py:89), within one ulp of this;
+* labels are passed through unchanged (one-hot for dense losses, (B,H,W,1) for sparse ones);
+* ``len() = floor(total_samples / batch_size)`` (tail dropped); the generator is stateful, ignores the
+  ``index`` argument and must be consumed sequentially; ``on_epoch_end`` composes a fresh permutation onto
+  the previous one (``sample_shuffle = sample_shuffle[s]``), seeded from the OS unless a seed is given.
+
+Batches are assembled with one fancy-indexing gather instead of the reference's per-sample Python loop
+(SURVEY 3.1 hot loop ii).  ``next_batch_u8`` is the engine's fast path: uint8 images + uint8 sparse labels,
+so the /255 happens on the GPU while the first conv loads the image."""
+from __future__ import annotations
+
+import logging as log
+from math import floor
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+
+class BatchGenerator:
+    def __init__(self, images: np.ndarray, labels: np.ndarray, batch_size: int, aug_fn_args: List[Tuple],
+                 aug_mode: str, aug_probs: Tuple, aug_fly: bool, preprocess_input_fn: Callable,
+                 seed: Optional[int] = None):
+        if aug_mode not in ("none", "one", "all"):
+            log.error(f"Unrecognized augmentation mode: {aug_mode}. Allowed values: 'none', 'one', 'all'. Exiting...")
+            exit(1)
+        if aug_mode != "none":
+            raise NotImplementedError("augmentation modes 'one'/'all' are outside the accelerated path "
+                                      "(SURVEY 8f row f4); use aug_mode='none'")
+        self.images_u8 = np.ascontiguousarray(images)
+        self.labels = labels
+        self.batch_size = int(batch_size)
+        self.aug_fn_args, self.aug_mode, self.aug_probs, self.aug_fly = aug_fn_args, aug_mode, aug_probs, aug_fly
+        self.preprocess_input_fn = preprocess_input_fn
+        self.total_full_images = self.images_u8.shape[0]
+        self.total_raw_samples = self.total_full_images
+        self.total_samples = self.total_raw_samples
+        self.total_augs = 0
+        self.image_height, self.image_width, self.num_channels = self.images_u8.shape[1:4]
+        self.labels_shape = self.labels.shape
+        self.batch_labels_shape = (self.batch_size,) + tuple(self.labels_shape[1:])
+        self.sample_shuffle = np.arange(self.total_full_images)
+        self.num_batches = int(floor(1.0 * self.total_samples / self.batch_size))
+        self._rng = np.random.default_rng(seed)  # seed=None: OS entropy, as the reference's np.random.seed()
+        self._sparse_cache = None
+        self.batch_counter = self.full_counter = self.aug_counter = 0
+        self.handle_epoch_end()
+
+    def _next_indices(self) -> np.ndarray:
+        idx = np.empty(self.batch_size, dtype=np.int64)
+        for k in range(self.batch_size):
+            idx[k] = self.sample_shuffle[self.full_counter]
+            self.full_counter += 1
+            if self.full_counter == self.total_full_images:
+                self.full_counter = 0
+        self.batch_counter += 1
+        if self.batch_counter == self.num_batches:
+            self.batch_counter = 0
+        return idx
+
+    def get_batch_list(self):
+        idx = self._next_indices()
+        batch_images = (self.images_u8[idx].astype(np.float32)) / np.float32(255.0)
+        batch_labels = np.asarray(self.labels[idx], dtype=np.float64)  # the reference's label buffer is float64
+        return [batch_images, batch_labels]
+
+    def sparse_labels(self) -> np.ndarray:
+        """uint8 (N,H,W) class map of the label array (argmax of a one-hot array, or the squeezed sparse map)."""
+        if self._sparse_cache is None:
+            lab = self.labels
+            if lab.ndim == 4 and lab.shape[-1] > 1:
+                lab = np.argmax(lab, axis=-1)
+            elif lab.ndim == 4:
+                lab = lab[..., 0]
+            self._sparse_cache = np.ascontiguousarray(lab.astype(np.uint8))
+        return self._sparse_cache
+
+    def next_batch_u8(self):
+        idx = self._next_indices()
+        return self.images_u8[idx], self.sparse_labels()[idx]
+
+    def handle_epoch_end(self):
+        self.batch_counter = 0
+        self.full_counter = 0
+        self.aug_counter = 0
+        s = self._rng.permutation(self.total_raw_samples)
+        self.sample_shuffle = self.sample_shuffle[s]
+
+
+class DataGenerator:
+    """``keras.utils.Sequence`` duck type: ``__len__``, ``__getitem__``, ``on_epoch_end``."""
+
+    oct_fast_path = True
+
+    def __init__(self, images: np.ndarray, labels: np.ndarray, batch_size: int, aug_fn_args: List[Tuple],
+                 aug_mode: str, aug_probs: Tuple, aug_fly: bool, preprocess_input_fn: Callable,
+                 seed: Optional[int] = None):
+        self.batch_gen = BatchGenerator(images=images, labels=labels, batch_size=batch_size, aug_fn_args=aug_fn_args,
+                                        aug_mode=aug_mode, aug_probs=aug_probs, aug_fly=aug_fly,
+                                        preprocess_input_fn=preprocess_input_fn, seed=seed)
+
+    def __len__(self):
+        return self.batch_gen.num_batches
+
+    def __getitem__(self, index):
+        X, y = self.batch_gen.get_batch_list()
+        return X, y
+
+    def next_batch_u8(self):
+        return self.batch_gen.next_batch_u8()
+
+    def on_epoch_end(self):
+        self.batch_gen.handle_epoch_end()
+
+    def get_total_samples(self) -> int:
+        return self.batch_gen.total_samples

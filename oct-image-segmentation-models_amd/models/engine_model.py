@@ -1,0 +1,358 @@
+"""``Model``: the duck-typed subset of ``tf.keras.Model`` that the reference's callers use
+(``compile/fit/predict/summary/save/get_weights/set_weights/stop_training``, ``.name``,
+``.output.shape[-1]``), backed by the HIP engine instead of TensorFlow.
+
+Reference call sites this object serves: training/training.py:262-266 (compile), :345,:400 (summary),
+:401-407 (fit with Sequence generators + callbacks), evaluation/evaluation.py:129-135 and
+prediction/prediction.py:75-81 (predict), evaluation_parameters.py:85 (``output.shape[-1]``).
+
+Data parallelism: when ``torch.distributed`` is initialised (one process per GPU), ``fit`` takes this rank's
+contiguous slice of every GLOBAL batch the generator yields, scales the loss by 1/world and sum-all-reduces
+the flat gradient buffer -- the semantics of ``MirroredStrategy`` (training.py:185-188,243).
+"""
+from __future__ import annotations
+
+import json
+import time
+from pathlib import Path
+from types import SimpleNamespace
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .. import parallel
+from .._hip import OctError
+
+WEIGHTS_FORMAT = "oct_unet_weights_v1"
+
+
+class Callback:
+    """Minimal ``keras.callbacks.Callback`` protocol."""
+    model = None
+
+    def set_model(self, model): self.model = model
+    def on_train_begin(self, logs=None): pass
+    def on_train_end(self, logs=None): pass
+    def on_epoch_begin(self, epoch, logs=None): pass
+    def on_epoch_end(self, epoch, logs=None): pass
+
+
+class ModelCheckpoint(Callback):
+    """``ModelCheckpoint(filepath, save_best_only, monitor, mode)`` as used at training.py:319-326;
+    ``filepath`` may contain ``{epoch:02d}`` (1-based)."""
+
+    def __init__(self, filepath, save_best_only=False, monitor="val_loss", mode="auto", verbose=0):
+        self.filepath, self.save_best_only, self.monitor = str(filepath), save_best_only, monitor
+        if mode == "auto":
+            mode = "max" if ("acc" in monitor or "dice" in monitor) else "min"
+        self.sign = 1.0 if mode == "max" else -1.0
+        self.best = -np.inf
+        self.saved: List[str] = []
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs or {}
+        path = self.filepath.format(epoch=epoch + 1, **logs)
+        if self.save_best_only:
+            cur = logs.get(self.monitor)
+            if cur is None or not np.isfinite(cur) or self.sign * cur <= self.best:
+                return
+            self.best = self.sign * cur
+        self.saved.append(str(self.model.save(path)))
+
+
+class EarlyStopping(Callback):
+    """``EarlyStopping(monitor, mode, patience, restore_best_weights)`` as used at training.py:335-342."""
+
+    def __init__(self, monitor="val_loss", mode="auto", patience=0, restore_best_weights=False, min_delta=0.0):
+        if mode == "auto":
+            mode = "max" if ("acc" in monitor or "dice" in monitor) else "min"
+        self.monitor, self.patience, self.restore_best_weights, self.min_delta = monitor, patience, restore_best_weights, min_delta
+        self.sign = 1.0 if mode == "max" else -1.0
+        self.best, self.wait, self.best_weights, self.stopped_epoch = -np.inf, 0, None, 0
+
+    def on_train_begin(self, logs=None):
+        self.best, self.wait, self.best_weights, self.stopped_epoch = -np.inf, 0, None, 0
+
+    def on_epoch_end(self, epoch, logs=None):
+        cur = (logs or {}).get(self.monitor)
+        if cur is None:
+            return
+        if self.restore_best_weights and self.best_weights is None:
+            self.best_weights = self.model.get_weights()
+        if np.isfinite(cur) and self.sign * cur - self.min_delta > self.best:
+            self.best, self.wait = self.sign * cur, 0
+            if self.restore_best_weights:
+                self.best_weights = self.model.get_weights()
+            return
+        self.wait += 1
+        if self.wait >= self.patience and epoch > 0:
+            self.stopped_epoch = epoch
+            self.model.stop_training = True
+            if self.restore_best_weights and self.best_weights is not None:
+                self.model.set_weights(self.best_weights)
+
+
+class History(Callback):
+    def on_train_begin(self, logs=None):
+        self.history, self.epoch = {}, []
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.epoch.append(epoch)
+        for k, v in (logs or {}).items():
+            self.history.setdefault(k, []).append(v)
+
+
+class Model:
+    def __init__(self, name: str, config: dict, device: Optional[str] = None):
+        self.name = name
+        self.config = dict(config)
+        self.output = SimpleNamespace(shape=(None, None, None, int(config["num_classes"])))
+        self.stop_training = False
+        self.optimizer = None
+        self._loss_name = self._metric_name = None
+        self._engine = None
+        self._pending_weights = None
+        self._device = device
+        self.history = None
+
+    # ---- engine lifetime ----------------------------------------------------------------------------
+    def _dev(self):
+        if self._device is not None:
+            return torch.device(self._device)
+        _, local_rank, _ = parallel.env_rank()
+        return torch.device("cuda", local_rank if torch.cuda.is_available() and local_rank < max(torch.cuda.device_count(), 1) else 0)
+
+    def _ensure_engine(self, batch: int, training: bool):
+        from ..engine import UNetEngine
+        e = self._engine
+        if e is not None and e.cfg.max_batch >= batch and (e.cfg.training or not training):
+            return e
+        weights = e.get_weights() if e is not None else self._pending_weights
+        opt_state = None if e is None else (e._opt, e.opt_step)
+        rank, _, _ = parallel.env_rank()
+        c = self.config
+        self._engine = UNetEngine(
+            device=self._dev(), input_channels=c["input_channels"], num_classes=c["num_classes"],
+            image_height=c["image_height"], image_width=c["image_width"],
+            start_neurons=c.get("start_neurons", 8), pool_layers=c.get("pool_layers", 4),
+            conv_layers=c.get("conv_layers", 2), enc_kernel=tuple(c.get("enc_kernel", (3, 3))),
+            dec_kernel=tuple(c.get("dec_kernel", (2, 2))),
+            max_batch=max(batch, e.cfg.max_batch if e is not None else 1),
+            training=training or (e is not None and bool(e.cfg.training)),
+            seed=int(c.get("seed", 0)) * 1000003 + rank, init_seed=int(c.get("seed", 0)))
+        if weights is not None:
+            self._engine.set_weights(weights)
+        if opt_state is not None:
+            self._engine._opt, self._engine.opt_step = opt_state
+        self._pending_weights = None
+        return self._engine
+
+    @property
+    def engine(self):
+        return self._ensure_engine(1, False)
+
+    # ---- keras.Model surface -------------------------------------------------------------------------
+    def compile(self, optimizer=None, loss=None, metrics=None, **kwargs):
+        loss_name = getattr(loss, "oct_loss", None) if loss is not None else None
+        if loss is not None and loss_name not in ("dice_loss_macro", "dice_loss_micro"):
+            raise OctError("compile(loss=...): only the Dice losses from common.custom_losses are implemented by "
+                           "the HIP engine (the loss arithmetic is fused into the head kernel)")
+        metric_name = None
+        for m in metrics or []:
+            metric_name = getattr(m, "oct_metric", None)
+            if metric_name not in ("dice_coef_macro", "dice_coef_micro"):
+                raise OctError("compile(metrics=...): only dice_coef_macro / dice_coef_micro are implemented")
+        if optimizer is not None and not hasattr(optimizer, "apply"):
+            raise OctError("compile(optimizer=...): pass an optimizers.Adam / optimizers.SGD instance")
+        self.optimizer, self._loss_name, self._metric_name = optimizer, loss_name, metric_name
+
+    def count_params(self) -> int:
+        from ..engine import make_cfg
+        from .. import _hip
+        import ctypes as C
+        c = self.config
+        cfg = make_cfg(input_channels=c["input_channels"], num_classes=c["num_classes"], image_height=c["image_height"],
+                       image_width=c["image_width"], start_neurons=c.get("start_neurons", 8),
+                       pool_layers=c.get("pool_layers", 4), conv_layers=c.get("conv_layers", 2))
+        l = _hip.lib()
+        return int(l.oct_unet_param_count(C.byref(cfg)) + l.oct_unet_state_count(C.byref(cfg)))
+
+    def summary(self, print_fn=print):
+        from ..engine import make_cfg, layer_table
+        c = self.config
+        cfg = make_cfg(input_channels=c["input_channels"], num_classes=c["num_classes"], image_height=c["image_height"],
+                       image_width=c["image_width"], start_neurons=c.get("start_neurons", 8),
+                       pool_layers=c.get("pool_layers", 4), conv_layers=c.get("conv_layers", 2))
+        print_fn(f'Model: "{self.name}"  (MI355X HIP engine)')
+        print_fn(f"{'layer':14s}{'kernel':>8s}{'in':>6s}{'out':>6s}{'HxW':>12s}{'params':>10s}")
+        tot = 0
+        for L in layer_table(cfg):
+            n = L["kh"] * L["kw"] * L["cin"] * L["cout"] + L["cout"] + (4 * L["cout"] if L["has_bn"] else 0)
+            tot += n
+            print_fn(f"{L['name']:14s}{str(L['kh']) + 'x' + str(L['kw']):>8s}{L['cin']:>6d}{L['cout']:>6d}"
+                     f"{str(L['out_h']) + 'x' + str(L['out_w']):>12s}{n:>10d}")
+        print_fn(f"Total params: {tot}")
+
+    def get_weights(self):
+        if self._engine is None:
+            if self._pending_weights is not None:
+                return [np.array(w) for w in self._pending_weights]
+            return self.engine.get_weights()
+        return self._engine.get_weights()
+
+    def set_weights(self, weights):
+        if self._engine is None:
+            self._pending_weights = [np.asarray(w, np.float32) for w in weights]
+        else:
+            self._engine.set_weights(weights)
+
+    def save(self, filepath, **kwargs) -> Path:
+        """Write architecture config + weights (Keras ``get_weights()`` order) to an ``.npz`` container."""
+        path = Path(filepath)
+        if path.suffix != ".npz":
+            path = Path(str(path) + ".npz")
+        w = self.get_weights()
+        if parallel.world_size() > 1 and self._engine is not None:
+            # BN moving statistics are per replica; they are mean-reduced when read
+            avg = parallel.average_moving_stats(self._engine.state)
+            keep = self._engine.state.clone(); self._engine.state.copy_(avg)
+            w = self._engine.get_weights(); self._engine.state.copy_(keep)
+        payload = {f"w{i:03d}": a for i, a in enumerate(w)}
+        payload["format"] = np.array(WEIGHTS_FORMAT)
+        payload["name"] = np.array(self.name)
+        payload["config_json"] = np.array(json.dumps(self.config))
+        if parallel.env_rank()[0] == 0:
+            path.parent.mkdir(parents=True, exist_ok=True)
+            np.savez(path, **payload)
+        return path
+
+    # ---- training -------------------------------------------------------------------------------------
+    def _device_batch(self, seq, index, rank, world):
+        """One GLOBAL batch from the Sequence -> this rank's (x, sparse uint8 labels) device tensors."""
+        if getattr(seq, "oct_fast_path", False):
+            X, lab = seq.next_batch_u8()
+        else:
+            X, y = seq[index]
+            X = np.ascontiguousarray(X, dtype=np.float32)
+            y = np.asarray(y)
+            lab = (np.argmax(y, axis=-1) if (y.ndim == 4 and y.shape[-1] > 1) else y.reshape(y.shape[:3])).astype(np.uint8)
+        lo, hi = parallel.shard_batch(X.shape[0], rank, world)
+        dev = self._engine.device if self._engine is not None else self._dev()
+        x = torch.from_numpy(np.ascontiguousarray(X[lo:hi])).to(dev, non_blocking=True)
+        l = torch.from_numpy(np.ascontiguousarray(lab[lo:hi])).to(dev, non_blocking=True)
+        return x, l
+
+    def _run_epoch(self, seq, training: bool, rank: int, world: int):
+        macro = self._loss_name != "dice_loss_micro"
+        acc = None
+        n = len(seq)
+        for i in range(n):
+            x, lab = self._device_batch(seq, i, rank, world)
+            eng = self._ensure_engine(x.shape[0], training)
+            eng.forward(x, training=training, labels=lab, want_probs=False)
+            loss4 = eng.loss_dice()
+            if training:
+                eng.backward(lab, macro=macro, loss_scale=1.0 / world)
+                parallel.allreduce_gradients(eng.grads)
+                self.optimizer.apply(eng)
+            acc = loss4.clone() if acc is None else acc + loss4
+        if acc is None:
+            return {}
+        acc = acc / n
+        if world > 1:
+            torch.distributed.all_reduce(acc); acc /= world
+        v = acc.cpu().numpy()
+        out = {"loss": float(v[0] if macro else v[1])}
+        if self._metric_name:
+            out[self._metric_name] = float(v[2] if self._metric_name == "dice_coef_macro" else v[3])
+        return out
+
+    def fit(self, x=None, validation_data=None, epochs: int = 1, callbacks=None, verbose: int = 1,
+            initial_epoch: int = 0, **kwargs):
+        if self.optimizer is None or self._loss_name is None:
+            raise OctError("fit() before compile(optimizer=..., loss=...)")
+        rank, _, world = parallel.env_rank()
+        world = parallel.world_size() if world > 1 else 1
+        hist = History()
+        cbs = list(callbacks or []) + [hist]
+        for cb in cbs:
+            cb.set_model(self)
+        self.stop_training = False
+        for cb in cbs:
+            cb.on_train_begin({})
+        for epoch in range(initial_epoch, epochs):
+            for cb in cbs:
+                cb.on_epoch_begin(epoch, {})
+            t0 = time.time()
+            logs = self._run_epoch(x, True, rank, world)
+            if hasattr(x, "on_epoch_end"):
+                x.on_epoch_end()
+            if validation_data is not None:
+                vlogs = self._run_epoch(validation_data, False, rank, world)
+                logs.update({"val_" + k: v for k, v in vlogs.items()})
+                if hasattr(validation_data, "on_epoch_end"):
+                    validation_data.on_epoch_end()
+            if verbose and rank == 0:
+                msg = " - ".join(f"{k}: {v:.4f}" for k, v in logs.items())
+                print(f"Epoch {epoch + 1}/{epochs} - {time.time() - t0:.1f}s - {msg}")
+            for cb in cbs:
+                cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in cbs:
+            cb.on_train_end({})
+        self.history = hist
+        return hist
+
+    def evaluate(self, x, verbose: int = 0, **kwargs):
+        rank, _, world = parallel.env_rank()
+        world = parallel.world_size() if world > 1 else 1
+        logs = self._run_epoch(x, False, rank, world)
+        return [logs.get("loss")] + ([logs[self._metric_name]] if self._metric_name else [])
+
+    # ---- inference --------------------------------------------------------------------------------------
+    def predict(self, x, verbose=0, batch_size: Optional[int] = None, **kwargs) -> np.ndarray:
+        """(n,H,W,C) float input ALREADY preprocessed to [0,1] (or raw uint8) -> (n,H,W,num_classes) float32."""
+        x = np.asarray(x)
+        if x.dtype != np.uint8:
+            x = np.ascontiguousarray(x, dtype=np.float32)   # Keras casts the float64 the reference passes to float32
+        n = x.shape[0]
+        bs = int(batch_size or min(n, 32))
+        eng = self._ensure_engine(min(bs, n), False)
+        out = np.empty((n,) + tuple(x.shape[1:3]) + (self.config["num_classes"],), np.float32)
+        for lo in range(0, n, bs):
+            xb = torch.from_numpy(np.ascontiguousarray(x[lo:lo + bs])).to(eng.device)
+            probs, _ = eng.forward(xb, training=False)
+            out[lo:lo + bs] = probs.cpu().numpy()
+        return out
+
+    def predict_labels(self, x_u8: np.ndarray, batch_size: int = 32) -> np.ndarray:
+        """Raw uint8 images -> uint8 arg-max class maps (n,H,W), computed on the device (1 B/px back instead of
+        4*C B/px)."""
+        x_u8 = np.ascontiguousarray(x_u8)
+        n = x_u8.shape[0]
+        eng = self._ensure_engine(min(batch_size, n), False)
+        out = np.empty(x_u8.shape[:3], np.uint8)
+        for lo in range(0, n, batch_size):
+            xb = torch.from_numpy(x_u8[lo:lo + batch_size]).to(eng.device)
+            _, am = eng.forward(xb, training=False, want_probs=False, want_argmax=True)
+            out[lo:lo + batch_size] = am.cpu().numpy()
+        return out
+
+
+def load_model(path) -> Model:
+    """Counterpart of ``tf.keras.models.load_model(compile=False)`` for files written by ``Model.save``.
+    Only arrays and JSON are read (``allow_pickle=False``)."""
+    path = Path(path)
+    if not path.exists() and Path(str(path) + ".npz").exists():
+        path = Path(str(path) + ".npz")
+    with np.load(path, allow_pickle=False) as z:
+        if str(z["format"]) != WEIGHTS_FORMAT:
+            raise OctError(f"{path}: unknown weights format {z['format']}")
+        config = json.loads(str(z["config_json"]))
+        name = str(z["name"])
+        weights = [z[k] for k in sorted(k for k in z.files if k.startswith("w") and k[1:].isdigit())]
+    m = Model(name=name, config=config)
+    m.set_weights(weights)
+    return m

@@ -1,0 +1,75 @@
+"""Host post-process (min_path_processing) pinned by golden vectors captured from the REAL reference
+(tests/golden/make_min_path_golden.py).  Bit-exact: integer/index work."""
+import os
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "min_path_golden.npz"))
+CASES = [("a", 32, 48, 4), ("b", 40, 64, 3), ("c", 24, 20, 5)]
+
+
+@pytest.fixture(scope="module")
+def gs():
+    ge.build()
+    from oct_image_segmentation_models_amd.min_path_processing import graph_search
+    assert graph_search._native() is not None, "liboct_minpath.so was not built"
+    return graph_search
+
+
+def test_generate_boundary_matches_reference():
+    from oct_image_segmentation_models_amd.min_path_processing import utils
+    for tag, H, W, C in CASES:
+        got = np.swapaxes(utils.generate_boundary(G[f"{tag}_labels"], axis=1), 0, 1)
+        assert np.array_equal(got, G[f"{tag}_generate_boundary"])
+
+
+def test_graph_structure_matches_reference(gs):
+    for tag, H, W, C in CASES:
+        g = gs.create_graph_structure((W, H))
+        adj = G[f"{tag}_graph_adj"]
+        assert len(g) == adj.shape[0]
+        for v in range(len(g)):
+            assert g[v] == [int(n) for n in adj[v] if n >= 0], v
+    g2 = gs.create_graph_structure((6, 5), max_grad=2)
+    for v in range(len(g2)):
+        assert g2[v] == [int(n) for n in G["grad2_graph_adj"][v] if n >= 0]
+
+
+@pytest.mark.parametrize("native", [True, False])
+@pytest.mark.parametrize("kind", ["clean", "noisy", "grey", "empty"])
+def test_segment_maps_matches_reference(gs, kind, native, monkeypatch):
+    if not native:
+        monkeypatch.setattr(gs, "_native", lambda: None)   # pure-Python body of the same algorithm
+    for tag, H, W, C in CASES:
+        if not native and tag == "b" and kind in ("grey", "empty"):
+            continue  # keep the CPU suite short: the Python body is slow on dense maps
+        graph = gs.create_graph_structure((W, H))
+        preds, errors, norm = gs.segment_maps(G[f"{tag}_{kind}_maps_t"], G[f"{tag}_generate_boundary"][0], graph)
+        assert preds.dtype == np.uint16 and np.array_equal(preds, G[f"{tag}_{kind}_pred"]), (tag, kind)
+        assert np.array_equal(errors, G[f"{tag}_{kind}_errors"], equal_nan=True)
+        stats = np.stack(gs.calculate_overall_errors(errors))
+        assert np.allclose(stats, G[f"{tag}_{kind}_stats"], rtol=0, atol=1e-12, equal_nan=True)
+
+
+def test_calc_errors_invalid_truths(gs):
+    for tag, H, W, C in CASES:
+        t = G[f"{tag}_calc_errors_truth"]
+        got = np.stack([gs.calc_errors(G[f"{tag}_clean_pred"][k], t[k]) for k in range(C - 1)])
+        assert np.array_equal(got, G[f"{tag}_calc_errors"], equal_nan=True)
+
+
+def test_clean_maps_reproduce_truth_boundaries(gs):
+    # property at a larger size than the goldens: a clean boundary map delineates to the truth rows exactly
+    from oracle import unet_numpy as on
+    from oct_image_segmentation_models_amd.min_path_processing import utils
+    from oct_image_segmentation_models_amd.common import utils as cu
+    H, W, C = 128, 256, 4
+    _, labels = on.synth_scans(1, H, W, C, seed=3)
+    lab = labels[..., 0]
+    truths = np.swapaxes(utils.generate_boundary(lab, axis=1), 0, 1)[0]
+    maps = cu.convert_predictions_to_maps_semantic(cu.labels_to_categorical(lab, C))[0]
+    preds, errors, _ = gs.segment_maps(np.transpose(maps, (0, 2, 1)), truths, gs.create_graph_structure((W, H)))
+    assert np.array_equal(preds, truths) and np.all(errors == 0)
