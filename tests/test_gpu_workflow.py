@@ -1,0 +1,118 @@
+"""GPU end-to-end test of the drop-in workflow (BASELINE config[0] analogue: small synthetic dataset,
+3 boundaries = 4 classes, a few epochs): train_model -> evaluate_model (+graph search) -> predict, checked
+against the oracle / numpy definitions."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_numpy as on
+
+pytestmark = pytest.mark.gpu
+
+H, W, C = 64, 128, 4
+
+
+@pytest.fixture(scope="module")
+def trained(tmp_path_factory):
+    from oct_image_segmentation_models_amd import optimizers
+    from oct_image_segmentation_models_amd.common import h5io
+    from oct_image_segmentation_models_amd.training.training import train_model
+    from oct_image_segmentation_models_amd.training.training_parameters import TrainingParams
+    root = tmp_path_factory.mktemp("wf")
+    tr_i, tr_l = on.synth_scans(12, H, W, C, seed=1)
+    va_i, va_l = on.synth_scans(4, H, W, C, seed=2)
+    te_i, te_l = on.synth_scans(5, H, W, C, seed=3)
+    h5io.save(root / "data.hdf5", {"train_images": tr_i, "train_labels": tr_l, "val_images": va_i, "val_labels": va_l,
+                                   "test_images": te_i, "test_labels": te_l,
+                                   "test_images_source": np.array([f"scan_{i}.tiff".encode() for i in range(5)])})
+    tp = TrainingParams(model_architecture="unet", training_dataset_path=root / "data.hdf5", initial_model=None,
+                        results_location=root / "results", opt_con=optimizers.Adam, opt_params={"learning_rate": 4e-3},
+                        loss="dice_loss_macro", metric="dice_coef_macro", epochs=30, batch_size=4,
+                        model_hyperparameters={"pool_layers": 3}, patience=50, seed=7)
+    res = train_model(tp, None)
+    return root, res, (te_i, te_l)
+
+
+def test_train_model_outputs_and_learning(trained):
+    from oct_image_segmentation_models_amd.common import h5io
+    root, res, _ = trained
+    d = Path(res.save_foldername)
+    assert d.parent == root / "results" and d.name.endswith("_unet")
+    cfg = __import__("json").load(open(d / "model_config.json"))
+    assert cfg["num_classes"] == C and cfg["image_height"] == H and cfg["pool_layers"] == 3
+    tp = h5io.load(d / "training_params.hdf5")
+    assert bytes(tp["attr:loss_name"]).rstrip(b"\x00") == b"dice_loss_macro" and tp["attr:batch_size"] == 4
+    assert bytes(tp["attr:optimizer"]).rstrip(b"\x00") == b"Adam"
+    hist = res.history
+    assert set(hist) == {"loss", "dice_coef_macro", "val_loss", "val_dice_coef_macro"} and len(hist["loss"]) == 30
+    assert hist["loss"][-1] < 0.6 * hist["loss"][0] and hist["val_dice_coef_macro"][-1] > 0.6
+    stats = h5io.load(d / "stats_epoch30.hdf5")
+    assert len(stats["train_loss"]) == 30 and not h5io.exists(d / "stats_epoch29.hdf5")   # rolling file
+    assert np.allclose(stats["val_acc"], hist["val_dice_coef_macro"])
+    assert len(res.checkpoints) >= 1 and all(Path(p).exists() for p in res.checkpoints)   # save_best_only
+    best = int(np.argmax(hist["val_dice_coef_macro"])) + 1
+    assert Path(res.checkpoints[-1]).name.startswith(f"model_epoch{best:02d}")
+
+
+def test_evaluate_and_predict_match_engine_and_numpy_definitions(trained):
+    from oct_image_segmentation_models_amd.common import custom_metrics, h5io, utils as cu
+    from oct_image_segmentation_models_amd.common.dataset import Dataset
+    from oct_image_segmentation_models_amd.evaluation import eval_model
+    from oct_image_segmentation_models_amd.evaluation.evaluation_parameters import EvaluationParameters, EvaluationSaveParams
+    from oct_image_segmentation_models_amd.prediction import predict
+    from oct_image_segmentation_models_amd.prediction.prediction_parameters import PredictionParams, PredictionSaveParams
+    root, res, (te_i, te_l) = trained
+    ckpt = Path(res.checkpoints[-1])
+    ep = EvaluationParameters(model_path=ckpt, mlflow_tracking_uri=None, mlflow_run_uuid=None,
+                              test_dataset_path=root / "data.hdf5", save_foldername=root / "eval",
+                              save_params=EvaluationSaveParams(categorical_pred=True), graph_search=True,
+                              metrics=["dice_coef_classes", "dice_coef_macro", "dice_coef_micro"], batch_size=2)
+    assert ep.num_classes == C and ep.loaded_model.name == "unet"
+    outs = eval_model(ep)
+    assert len(outs) == 5
+    # the loaded checkpoint reproduces Model.predict (float path, preprocessed as the reference does)
+    probs = ep.loaded_model.predict(te_i / 255.0, batch_size=3)
+    assert probs.shape == (5, H, W, C) and probs.dtype == np.float32
+    am = probs.argmax(-1)
+    for i, o in enumerate(outs):
+        assert str(o.image_name) == f"scan_{i}.tiff"
+        assert np.array_equal(o.predicted_labels, am[i])
+        cat = cu.labels_to_categorical(am[i:i + 1], C)
+        assert np.array_equal(o.boundary_maps, on.convert_predictions_to_maps_semantic(cat)[0])
+        y = on.one_hot(te_l[i:i + 1], C, np.float64)
+        f = h5io.load(o.image_output_dir / "evaluation_results.hdf5")
+        assert np.allclose(f["dice_coef_classes"], on.soft_dice_class(np.transpose(y, (0, 3, 1, 2)), cat)[0])
+        assert abs(f["dice_coef_macro"][0] - on.dice_coef_macro(y, np.transpose(cat, (0, 2, 3, 1)))) < 1e-6
+        assert f["predicted_segmentation_map"].dtype == np.uint8 and f["raw_segs"].shape == (C - 1, W)
+        g = h5io.load(o.image_output_dir / "gs_evaluation_results.hdf5")
+        assert g["gs_pred_segs"].shape == (C - 1, W) and g["errors"].shape == (C - 1, W)
+        assert np.array_equal(g["gs_pred_segs"], o.gs_pred_segs)
+        assert np.nanmean(np.abs(o.errors)) < 3.0          # trained net delineates within a few pixels
+        assert (root / "eval" / f"image_{i}" / "gs_boundaries.csv").exists()
+    overall = h5io.load(root / "eval" / "overall_evaluation_results.hdf5")
+    assert overall["dice_coef_classes"].shape == (5, C) and overall["mean_dice_coef_macro"] > 0.6
+    assert overall["errors"].shape == (5, C - 1, W)
+
+    ds = Dataset(te_i, [Path(f"scan_{i}.tiff") for i in range(5)], [root / "pred" / f"image_{i}" for i in range(5)])
+    pp = PredictionParams(model_path=ckpt, mlflow_tracking_uri=None, mlflow_run_uuid=None, dataset=ds,
+                          config_output_dir=root / "pred", save_params=PredictionSaveParams(), graph_search=True, batch_size=4)
+    pouts = predict(pp)
+    for o, p in zip(outs, pouts):
+        assert np.array_equal(o.predicted_labels, p.predicted_labels) and np.array_equal(o.gs_pred_segs, p.gs_pred_segs)
+        info = h5io.load(p.image_output_dir / "prediction_info.hdf5")
+        assert np.array_equal(info["predicted_labels"], p.predicted_labels) and "attr:convert_time" in info
+
+
+def test_resume_from_initial_model(trained, tmp_path):
+    from oct_image_segmentation_models_amd import optimizers
+    from oct_image_segmentation_models_amd.training.training import train
+    from oct_image_segmentation_models_amd.training.training_parameters import TrainingParams
+    root, res, _ = trained
+    tp = TrainingParams(model_architecture=None, training_dataset_path=root / "data.hdf5",
+                        initial_model=Path(res.checkpoints[-1]), results_location=tmp_path / "r2",
+                        opt_con=optimizers.SGD, opt_params={"learning_rate": 1e-3, "momentum": 0.9},
+                        loss="dice_loss_micro", metric="dice_coef_micro", epochs=2, batch_size=4, early_stopping=False)
+    r2 = train(tp, None)
+    assert r2.history["val_dice_coef_micro"][0] > 0.6      # starts from the trained weights, not from scratch
