@@ -12,6 +12,7 @@ from oracle import unet_numpy as on
 pytestmark = pytest.mark.gpu
 
 H, W, C = 64, 128, 4
+EPOCHS = 120   # 360 steps: BN moving statistics (momentum 0.99) need a few hundred steps to converge
 
 
 @pytest.fixture(scope="module")
@@ -29,7 +30,7 @@ def trained(tmp_path_factory):
                                    "test_images_source": np.array([f"scan_{i}.tiff".encode() for i in range(5)])})
     tp = TrainingParams(model_architecture="unet", training_dataset_path=root / "data.hdf5", initial_model=None,
                         results_location=root / "results", opt_con=optimizers.Adam, opt_params={"learning_rate": 4e-3},
-                        loss="dice_loss_macro", metric="dice_coef_macro", epochs=30, batch_size=4,
+                        loss="dice_loss_macro", metric="dice_coef_macro", epochs=EPOCHS, batch_size=4,
                         model_hyperparameters={"pool_layers": 3}, patience=50, seed=7)
     res = train_model(tp, None)
     return root, res, (te_i, te_l)
@@ -46,10 +47,10 @@ def test_train_model_outputs_and_learning(trained):
     assert bytes(tp["attr:loss_name"]).rstrip(b"\x00") == b"dice_loss_macro" and tp["attr:batch_size"] == 4
     assert bytes(tp["attr:optimizer"]).rstrip(b"\x00") == b"Adam"
     hist = res.history
-    assert set(hist) == {"loss", "dice_coef_macro", "val_loss", "val_dice_coef_macro"} and len(hist["loss"]) == 30
+    assert set(hist) == {"loss", "dice_coef_macro", "val_loss", "val_dice_coef_macro"} and len(hist["loss"]) == EPOCHS
     assert hist["loss"][-1] < 0.6 * hist["loss"][0] and hist["val_dice_coef_macro"][-1] > 0.6
-    stats = h5io.load(d / "stats_epoch30.hdf5")
-    assert len(stats["train_loss"]) == 30 and not h5io.exists(d / "stats_epoch29.hdf5")   # rolling file
+    stats = h5io.load(d / f"stats_epoch{EPOCHS:02d}.hdf5")
+    assert len(stats["train_loss"]) == EPOCHS and not h5io.exists(d / f"stats_epoch{EPOCHS - 1:02d}.hdf5")   # rolling file
     assert np.allclose(stats["val_acc"], hist["val_dice_coef_macro"])
     assert len(res.checkpoints) >= 1 and all(Path(p).exists() for p in res.checkpoints)   # save_best_only
     best = int(np.argmax(hist["val_dice_coef_macro"])) + 1
