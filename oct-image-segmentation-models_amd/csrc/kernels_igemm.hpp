@@ -1,0 +1,307 @@
+// MFMA implicit-GEMM convolution for gfx950 (fp32 in / fp32 accumulate: v_mfma_f32_32x32x2_f32 and
+// v_mfma_f32_16x16x4_f32 -- exact f32 FMA chains at the fp32 peak rate, 157 TF; MI355X_MICROARCH.md).
+//
+// One kernel template serves the forward convs AND backward-data:
+//     out[b, y, x, m] = sum_{tap, c}  Wt[tap][c][m] * In(b, pixel(y, x, tap), c)
+//   M (MFMA rows)  = output channels, tile 32 (C>=32) or 16 (thin layers)
+//   N (MFMA cols)  = 32 / 16 consecutive output pixels of one image row
+//   K              = taps x input channels, consumed in chunks of KC channels
+// * The input tile (with halo) is staged into LDS in PLANAR layout [c][row][col] with the consumer-side
+//   transform applied while loading (BN+ReLU affine, concat of two sources, dropout): 32 lanes of a B-operand
+//   read hit 32 consecutive banks -> conflict-free ds_read_b32.
+// * The weight chunk [tap][c][m] is staged into LDS with m fastest -> conflict-free A-operand reads.
+// * Addressing modes: A_NORMAL (3x3 'same'), A_UPF (2x2 conv over a nearest-upsampled low-res tile: the
+//   upsampled tensor is never materialised), A_DOWN2 (stride-2 3x3 gather over dz with effective weights =
+//   backward-data of the up-conv with UpSampling2D's 2x2 window sum folded in).
+// * Epilogues: EPI_FWD (bias, store z, per-channel sum / sum^2 partials), EPI_RAW (store gradient),
+//   EPI_MASK (ReLU mask (+dropout) from the producer's z, BN-backward partial sums, store g').
+#pragma once
+#include "common.hpp"
+
+namespace oct {
+
+enum { A_NORMAL = 0, A_UPF = 1, A_DOWN2 = 2 };
+enum { EPI_FWD = 0, EPI_RAW = 1, EPI_MASK = 2 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct IgemmArgs {
+    const float* x0; const float* ab0; int C0;   // input source 0 (+ BN record when F_AFF)
+    const float* x1; const float* ab1; int C1;   // source 1 of a concat (F_TWO)
+    int flags;                                   // F_AFF | F_TWO | F_DROP   (runtime: staging is not the hot loop)
+    int Cin;                                     // K channels in total
+    const float* w; int w_ld; int m_off;         // weights [taps][Cin][w_ld]; this launch covers columns m_off..m_off+Mout
+    const float* bias;                           // EPI_FWD
+    float* out; int Mout;                        // (B,Ho,Wo,Mout)
+    int Ho, Wo, Hi, Wi;                          // output / input-source spatial dims
+    int tiles_x, tiles;
+    float* part;                                 // [B*tiles][2*Mout] statistic partials (EPI_FWD / EPI_MASK) or nullptr
+    const float* zin; const float* bnin;         // EPI_MASK: producer's raw output (B,Ho,Wo,Mout) + its BN record
+    int drop_out;                                // EPI_MASK: the producer's output passes through dropout
+    DropCfg drop;
+};
+
+template <int SHAPE> struct MfmaShape;
+template <> struct MfmaShape<32> {
+    static constexpr int KS = 2, ACC = 16, QUADS = 4;
+    using acc_t = f32x16;
+    __device__ static inline acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    // channel (row of D) of quad q, element r for lane-half h:  (r&3) + 8*(reg>>2) + 4*h  with reg = 4q + r
+    __device__ static inline int quad_base(int q, int h) { return 8 * q + 4 * h; }
+};
+template <> struct MfmaShape<16> {
+    static constexpr int KS = 4, ACC = 4, QUADS = 1;
+    using acc_t = f32x4;
+    __device__ static inline acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static inline int quad_base(int q, int h) { return 4 * h; }
+};
+
+// sum N values over the lanes that share the upper lane bits (sub-group = lanes differing in bits < log2(2*OFF0)):
+// halving butterfly from offset OFF0 down to 1.  On return v[0] holds the total of value index
+// sub_chan<N,OFF0>(lane).
+template <int NFULL, int N, int OFF>
+__device__ inline void subgroup_reduce_rec(float (&v)[NFULL], int lane) {
+    if constexpr (OFF >= 1) {
+        if constexpr (N > 1) {
+            const bool upper = (lane & OFF) != 0;
+#pragma unroll
+            for (int i = 0; i < N / 2; ++i) {
+                const float send = upper ? v[i] : v[i + N / 2];
+                const float keep = upper ? v[i + N / 2] : v[i];
+                v[i] = keep + __shfl_xor(send, OFF, 64);
+            }
+            subgroup_reduce_rec<NFULL, N / 2, OFF / 2>(v, lane);
+        } else {
+            v[0] += __shfl_xor(v[0], OFF, 64);
+            subgroup_reduce_rec<NFULL, 1, OFF / 2>(v, lane);
+        }
+    }
+}
+template <int N, int OFF0>
+__device__ inline int sub_chan(int lane) {
+    int c = 0, n = N, off = OFF0;
+    while (n > 1) { if (lane & off) c += n / 2; n >>= 1; off >>= 1; }
+    return c;
+}
+
+// grid (tiles, ceil(Mout/MB), B), block 256 = 4 waves arranged WN (pixel tiles) x WM (channel tiles)
+template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN>
+__global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
+    using S = MfmaShape<SHAPE>;
+    constexpr int MT = SHAPE, NT = SHAPE, KS = S::KS, ACC = S::ACC, QUADS = S::QUADS;
+    constexpr int TW = 32, NPR = TW / NT, NTB = TH * NPR, MTB = MB / MT, WM = 4 / WN;
+    constexpr int NTW = NTB / WN, MTW = MTB / WM, TAPS = KH * KH;
+    static_assert(NTB % WN == 0 && MTB % WM == 0 && NTW >= 1 && MTW >= 1, "bad wave arrangement");
+    constexpr int KC = (AMODE == A_DOWN2 && TH >= 8) ? 8 : 16;
+    constexpr int IH = AMODE == A_NORMAL ? TH + KH - 1 : (AMODE == A_UPF ? TH / 2 + 1 : 2 * TH + 1);
+    constexpr int IW = AMODE == A_NORMAL ? TW + KH - 1 : (AMODE == A_UPF ? TW / 2 + 1 : 2 * TW + 1);
+    constexpr int PLANE = ((IH * IW + 15) / 32) * 32 + 16;   // == 16 (mod 32): the two k-rows of a 16x16x4 read hit disjoint banks
+    constexpr int RED = 4 * 2 * MTW * MT;
+
+    __shared__ float Is[KC * PLANE];
+    __shared__ float Ws[TAPS * KC * MB];
+    __shared__ float red[RED];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
+    const int j = lane & (NT - 1), kk = lane / NT, h = kk;   // B/A operand: column j (or row i), k index kk; D: lane half/quarter h
+    const int tile = blockIdx.x, b = blockIdx.z, m0 = blockIdx.y * MB;
+    const int x0 = (tile % A.tiles_x) * TW, y0 = (tile / A.tiles_x) * TH;
+    const int iy0 = AMODE == A_NORMAL ? y0 - (KH - 1) / 2 : (AMODE == A_UPF ? y0 / 2 : 2 * y0 - 1);
+    const int ix0 = AMODE == A_NORMAL ? x0 - (KH - 1) / 2 : (AMODE == A_UPF ? x0 / 2 : 2 * x0 - 1);
+
+    typename S::acc_t acc[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < ACC; ++r) acc[mt][nt][r] = 0.f;
+
+    // per-lane LDS offsets of the B operand for each of this wave's pixel tiles (tap offset added in the loop)
+    int boff[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
+        boff[nt] = AMODE == A_NORMAL ? r * IW + xs : (AMODE == A_UPF ? 0 : (2 * r) * IW + 2 * xs);
+    }
+
+    for (int c0 = 0; c0 < A.Cin; c0 += KC) {
+        __syncthreads();   // previous chunk fully consumed
+        // ---- stage the input chunk: NHWC global (float4 = 4 channels of a pixel) -> planar LDS, transform on load ----
+        for (int e = tid; e < (KC / 4) * IH * IW; e += kBlock) {
+            const int q = e % (KC / 4), p = e / (KC / 4), lx = p % IW, ly = p / IW;
+            const int gy = iy0 + ly, gx = ix0 + lx, c = c0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
+                const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
+                const float* src = A.x0; const float* ab = A.ab0; int C = A.C0, cc = c;
+                if ((A.flags & F_TWO) && c >= A.C0) { src = A.x1; ab = A.ab1; C = A.C1; cc = c - A.C0; }
+                v = ld4(src + pix * C + cc);
+                if (A.flags & F_AFF) {
+                    const float4 a = ld4(ab + cc), bb = ld4(ab + C + cc);
+                    v.x = fmaxf(fmaf(a.x, v.x, bb.x), 0.f); v.y = fmaxf(fmaf(a.y, v.y, bb.y), 0.f);
+                    v.z = fmaxf(fmaf(a.z, v.z, bb.z), 0.f); v.w = fmaxf(fmaf(a.w, v.w, bb.w), 0.f);
+                }
+                if (A.flags & F_DROP) {
+                    const uint32_t el = (uint32_t)(pix * C + cc);
+                    v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
+                    v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
+                }
+            }
+            float* d = Is + (4 * q) * PLANE + ly * IW + lx;
+            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
+        }
+        // ---- stage the weight chunk [tap][kc][m] ----
+        for (int e = tid; e < TAPS * KC * (MB / 4); e += kBlock) {
+            const int m4 = e % (MB / 4), r = e / (MB / 4), kc = r % KC, tap = r / KC;
+            const int c = c0 + kc, m = m0 + 4 * m4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < A.Cin && m < A.Mout) v = ld4(A.w + ((size_t)tap * A.Cin + c) * A.w_ld + A.m_off + m);
+            st4(Ws + (tap * KC + kc) * MB + 4 * m4, v);
+        }
+        __syncthreads();
+        // ---- MFMA over taps x k-steps ----
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < KH; ++kx) {
+                const int tap = ky * KH + kx;
+                int tapoff[NTW];
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    if constexpr (AMODE == A_UPF) {
+                        const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
+                        tapoff[nt] = ((r + ky) >> 1) * IW + ((xs + kx) >> 1);
+                    } else {
+                        tapoff[nt] = boff[nt] + ky * IW + kx;
+                    }
+                }
+#pragma unroll 2
+                for (int ks = 0; ks < KC / KS; ++ks) {
+                    const int kc = ks * KS + kk;
+                    float a[MTW], bv[NTW];
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) a[mt] = Ws[(tap * KC + kc) * MB + (wm * MTW + mt) * MT + j];
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) bv[nt] = Is[kc * PLANE + tapoff[nt]];
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = S::mfma(a[mt], bv[nt], acc[mt][nt]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    float s1[MTW][ACC], s2[MTW][ACC];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < ACC; ++r) { s1[mt][r] = 0.f; s2[mt][r] = 0.f; }
+
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
+        const int y = y0 + r, x = x0 + xs;
+        const bool pvalid = y < A.Ho && x < A.Wo;
+        const size_t pix = pvalid ? ((size_t)b * A.Ho + y) * A.Wo + x : 0;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+            for (int q = 0; q < QUADS; ++q) {
+                const int m = m0 + (wm * MTW + mt) * MT + S::quad_base(q, h);
+                const bool valid = pvalid && m < A.Mout;
+                float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                if constexpr (EPI == EPI_FWD) {
+                    if (valid) {
+                        const float4 bs = ld4(A.bias + A.m_off + m);
+                        v[0] += bs.x; v[1] += bs.y; v[2] += bs.z; v[3] += bs.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float u = valid ? v[k] : 0.f;
+                        s1[mt][4 * q + k] += u; s2[mt][4 * q + k] += u * u;
+                    }
+                } else if constexpr (EPI == EPI_MASK) {
+                    const float4 zq = valid ? ld4(A.zin + pix * A.Mout + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float zz[4] = {zq.x, zq.y, zq.z, zq.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = valid ? m + k : 0;
+                        const float yv = fmaf(A.bnin[BN_A * A.Mout + c], zz[k], A.bnin[BN_B * A.Mout + c]);
+                        float gv = v[k];
+                        if (A.drop_out) gv *= drop_mul(A.drop, (uint32_t)(pix * A.Mout + c));
+                        gv = (valid && yv > 0.f) ? gv : 0.f;
+                        const float xh = (zz[k] - A.bnin[BN_MEAN * A.Mout + c]) * A.bnin[BN_RSTD * A.Mout + c];
+                        v[k] = gv; s1[mt][4 * q + k] += gv; s2[mt][4 * q + k] += gv * xh;
+                    }
+                }
+                if (valid) st4(A.out + pix * A.Mout + m, make_float4(v[0], v[1], v[2], v[3]));
+            }
+        }
+    }
+
+    if constexpr (EPI != EPI_RAW) {
+        if (A.part) {
+            // lanes sharing h hold the same channel set for different pixels: reduce over the pixel lanes
+            constexpr int OFF0 = NT / 2;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                subgroup_reduce_rec<ACC, ACC, OFF0>(s1[mt], lane);
+                subgroup_reduce_rec<ACC, ACC, OFF0>(s2[mt], lane);
+                const int ci = sub_chan<ACC, OFF0>(lane);                      // value index this lane now holds
+                const int mloc = S::quad_base(ci >> 2, h) + (ci & 3);          // channel within the M tile
+                red[((wave * 2 + 0) * MTW + mt) * MT + mloc] = s1[mt][0];
+                red[((wave * 2 + 1) * MTW + mt) * MT + mloc] = s2[mt][0];
+            }
+            __syncthreads();
+            if (tid < 2 * MB) {
+                const int stat = tid / MB, ml = tid % MB;            // channel ml of this block's MB
+                const int mtile = ml / MT, wmm = mtile / MTW, mt = mtile % MTW, mloc = ml % MT;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) s += red[(((wmm * WN + w) * 2 + stat) * MTW + mt) * MT + mloc];
+                if (m0 + ml < A.Mout)
+                    A.part[((size_t)b * A.tiles + tile) * (2 * A.Mout) + (size_t)stat * A.Mout + m0 + ml] = s;
+            }
+        }
+    }
+}
+
+// ---- per-step weight preparation for backward-data: transposed+flipped kernels, effective up-conv kernels ----
+struct WtDesc {
+    const float* w; float* wt;
+    int kh, cin, cout, mode;     // mode 0: 3x3 -> WT[8-tap][co][ci];  mode 1: 2x2 -> Weff[a][b][co][ci] (3x3 stride-2 gather)
+    unsigned start, count;       // element range of this layer in the flattened launch
+};
+
+__global__ __launch_bounds__(kBlock) void prep_wt_k(const WtDesc* __restrict__ descs, int nd, unsigned total) {
+    for (unsigned e = blockIdx.x * kBlock + threadIdx.x; e < total; e += gridDim.x * kBlock) {
+        int d = 0;
+        while (d + 1 < nd && e >= descs[d + 1].start) ++d;
+        const WtDesc D = descs[d];
+        const unsigned r = e - D.start;
+        const int ci = r % D.cin, co = (r / D.cin) % D.cout, tap = r / (D.cin * D.cout);
+        float v;
+        if (D.mode == 0) {
+            v = D.w[((size_t)(8 - tap) * D.cin + ci) * D.cout + co];
+        } else {
+            const int a = tap / 3, bq = tap % 3;
+            v = 0.f;
+            for (int ky = 0; ky < 2; ++ky) {
+                const bool yin = (a == 0 && ky == 1) || a == 1 || (a == 2 && ky == 0);
+                if (!yin) continue;
+                for (int kx = 0; kx < 2; ++kx) {
+                    const bool xin = (bq == 0 && kx == 1) || bq == 1 || (bq == 2 && kx == 0);
+                    if (xin) v += D.w[((size_t)(ky * 2 + kx) * D.cin + ci) * D.cout + co];
+                }
+            }
+        }
+        D.wt[r] = v;
+    }
+}
+
+}  // namespace oct

@@ -12,6 +12,7 @@
 #include "common.hpp"
 #include "kernels_bwd.hpp"
 #include "kernels_fwd.hpp"
+#include "kernels_igemm.hpp"
 
 using namespace oct;
 
@@ -59,6 +60,7 @@ struct Layer {
     size_t w_off, b_off, gamma_off, beta_off, mm_off, mv_off;
     // workspace (device) pointers
     float* z = nullptr; float* g = nullptr; float* bn = nullptr;
+    float* wt = nullptr;   // backward-data weights: transposed+flipped 3x3, or effective 3x3 of an up-conv (9*cin*cout)
 };
 
 struct Plan {
@@ -160,6 +162,7 @@ struct oct_unet {
     float* dw_part = nullptr;
     float* dice_part = nullptr; double* dice_bc = nullptr; float* loss4 = nullptr;
     float* dlogits = nullptr;
+    WtDesc* wt_descs = nullptr; int n_wt = 0; unsigned wt_total = 0;
     unsigned long long drop_step = 0; int drop_advance = 0;
     int last_B = 0; int last_training = 0; int have_dice = 0; int dice_final = 0;
     const void* last_x = nullptr; int last_u8 = 0;   // input of the last forward (first layer's dW re-reads it)
@@ -180,8 +183,10 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
         float* z = l.has_bn ? (float*)take(n * 4) : nullptr;   // the head writes straight to the caller's buffers
         float* g = c.training && l.has_bn ? (float*)take(n * 4) : nullptr;
         float* bn = l.has_bn ? (float*)take((size_t)BN_ARRAYS * l.cout * 4) : nullptr;
-        if (base) { l.z = z; l.g = g; l.bn = bn; }
-        stat_max = std::max(stat_max, B * tiles_of(l.H, l.W) * 2 * (size_t)std::max(l.cout, l.cin));
+        float* wt = (c.training && l.has_bn && l.src != SRC_INPUT) ? (float*)take((size_t)9 * l.cin * l.cout * 4) : nullptr;
+        if (base) { l.z = z; l.g = g; l.bn = bn; l.wt = wt; }
+        // statistic partial rows: one per pixel tile; the MFMA kernels may use tiles as small as 2 x 32 pixels
+        stat_max = std::max(stat_max, B * cdiv(l.H, 2) * cdiv(l.W, kTileX) * 2 * (size_t)std::max(l.cout, l.cin));
         if (c.training) {
             const size_t wsz = (size_t)l.kh * l.kw * l.cin * l.cout + l.cout;
             dw_max = std::max(dw_max, (size_t)dw_npb(l, c.max_batch, dw_ci_t(l), dw_co_t(l)) * wsz);
@@ -201,6 +206,8 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
     double* bc = (double*)take((B * 8 * 2 + 2) * 8);
     float* l4 = (float*)take(4 * 4);
     float* dl = c.training ? (float*)take(B * c.H * c.W * c.n_cls * 4) : nullptr;
+    WtDesc* wd = c.training ? (WtDesc*)take(pl.L.size() * sizeof(WtDesc)) : nullptr;
+    if (h) h->wt_descs = wd;
     if (h) { h->stat_part = sp; h->dw_part = dwp; h->dice_part = dp; h->dice_bc = bc; h->loss4 = l4; h->dlogits = dl; }
     return off;
 }
@@ -251,6 +258,33 @@ SrcDesc src_of(const oct_unet* h, int li, const void* x_in, int x_is_u8) {
     return d;
 }
 
+// ---- MFMA implicit-GEMM launcher: picks the MFMA shape from the channel count and the pixel tile from the grid size ----
+template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN>
+int launch_igemm_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes) {
+    a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH);
+    dim3 grid(a.tiles, cdiv(a.Mout, MB), B), block(kBlock);
+    char nm[48]; snprintf(nm, sizeof nm, "conv_igemm_k<%d,%d,%d,%d,%d,%d>", SHAPE, KH, AMODE, EPI, TH, MB);
+    ProfScope ps(s, nm, layer, flops, bytes);
+    conv_igemm_k<SHAPE, KH, AMODE, EPI, TH, MB, WN><<<grid, block, 0, s>>>(a);
+    HIP_OK(hipGetLastError());
+    return a.tiles;   // > 0: number of pixel tiles per image (rows of statistic partials = B * tiles)
+}
+
+template <int KH, int AMODE, int EPI>
+int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes) {
+    auto blocks = [&](int th, int mb) { return (long)B * cdiv(a.Ho, th) * cdiv(a.Wo, 32) * cdiv(a.Mout, mb); };
+    if (a.Mout <= 16) {
+        if (blocks(8, 16) >= 512) return launch_igemm_geo<16, KH, AMODE, EPI, 8, 16, 4>(a, B, s, layer, flops, bytes);
+        return launch_igemm_geo<16, KH, AMODE, EPI, 4, 16, 4>(a, B, s, layer, flops, bytes);
+    }
+    if (a.Mout <= 32) {
+        if (blocks(8, 32) >= 512) return launch_igemm_geo<32, KH, AMODE, EPI, 8, 32, 4>(a, B, s, layer, flops, bytes);
+        return launch_igemm_geo<32, KH, AMODE, EPI, 4, 32, 4>(a, B, s, layer, flops, bytes);
+    }
+    if (blocks(4, 64) >= 512) return launch_igemm_geo<32, KH, AMODE, EPI, 4, 64, 4>(a, B, s, layer, flops, bytes);
+    return launch_igemm_geo<32, KH, AMODE, EPI, 2, 64, 2>(a, B, s, layer, flops, bytes);
+}
+
 // algorithmic bytes of a conv's logical input, read once: low-res tensor for an up-conv, both
 // halves of a concat, the pooled tensor after a pool, 1 B/px for a u8 image
 double in_bytes(const Layer& l, int B, int x_is_u8) {
@@ -274,6 +308,19 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
     const double px = (double)B * l.H * l.W, fl = 2.0 * l.kh * l.kw * l.cin * l.cout * px;
     const double by = in_bytes(l, B, x_is_u8) + px * l.cout * 4;   // logical input once + output once
     int rc;
+    int stat_rows = B * a.tiles;
+    if (l.src != SRC_INPUT && l.cin % 4 == 0) {   // MFMA path (every conv except the 1-channel first layer)
+        IgemmArgs g{};
+        g.x0 = (const float*)sd.x0; g.ab0 = sd.ab0; g.C0 = sd.C0; g.x1 = sd.x1; g.ab1 = sd.ab1; g.C1 = sd.C1;
+        g.flags = sd.flags | (drop ? F_DROP : 0);
+        g.Cin = l.cin; g.w = a.w; g.w_ld = l.cout; g.m_off = 0; g.bias = a.bias; g.out = l.z; g.Mout = l.cout;
+        g.Ho = l.H; g.Wo = l.W; g.Hi = l.src == SRC_UP ? l.H / 2 : l.H; g.Wi = l.src == SRC_UP ? l.W / 2 : l.W;
+        g.part = a.part; g.drop = a.drop;
+        const int t = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, B, s, l.name, fl, by)
+                                      : launch_igemm<3, A_NORMAL, EPI_FWD>(g, B, s, l.name, fl, by);
+        if (t < 0) return t;
+        stat_rows = B * t; rc = 0;
+    } else
     switch (l.src) {
         case SRC_INPUT: rc = x_is_u8 ? launch_conv_fwd_co<3, F_U8>(a, B, s, l.name, fl, by) : launch_conv_fwd_co<3, 0>(a, B, s, l.name, fl, by); break;
         case SRC_POOL: rc = launch_conv_fwd_co<3, 0>(a, B, s, l.name, fl, by); break;
@@ -284,9 +331,9 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
     }
     if (rc) return rc;
     if (l.has_bn && training) {
-        ProfScope ps(s, "bn_fwd_finalize_k", l.name, 0, (double)B * a.tiles * 2 * l.cout * 4);
+        ProfScope ps(s, "bn_fwd_finalize_k", l.name, 0, (double)stat_rows * 2 * l.cout * 4);
         BnFinArgs f{};
-        f.part = h->stat_part; f.nblk = B * a.tiles; f.C = l.cout; f.count = (double)B * l.H * l.W;
+        f.part = h->stat_part; f.nblk = stat_rows; f.C = l.cout; f.count = (double)B * l.H * l.W;
         f.gamma = h->params + l.gamma_off; f.beta = h->params + l.beta_off; f.bn = l.bn;
         f.mm = h->state + l.mm_off; f.mv = h->state + l.mv_off;
         f.eps = h->cfg.bn_eps; f.momentum = h->cfg.bn_momentum; f.unbiased = h->cfg.bn_unbiased_moving_var;
@@ -427,20 +474,6 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const fl
     return 0;
 }
 
-template <int KH, bool UP, int EPI>
-int launch_dx(const ConvBwdDataArgs& a, int B, hipStream_t s, const char* layer) {
-    const int ci_t = std::min(chunk_of(a.Cg), 8);
-    dim3 grid(a.tiles, a.Cg / ci_t, B), block(kBlock);
-    const double px = (double)B * a.H * a.W, pxg = (double)B * a.Hg * a.Wg;
-    char nm[48]; snprintf(nm, sizeof nm, "conv_bwd_data_k<%d,%d,%d,%d>", KH, ci_t, (int)UP, EPI);
-    // dz once + gradient written once (+ producer's z once for the ReLU mask / BN-backward statistics)
-    ProfScope ps(s, nm, layer, 2.0 * KH * KH * a.Cg * a.Cout * px, px * a.Cout * 4 + pxg * a.Cg * 4 * (EPI == E_RAW ? 1 : 2));
-    if (ci_t == 8) conv_bwd_data_k<KH, 8, UP, EPI><<<grid, block, 0, s>>>(a);
-    else conv_bwd_data_k<KH, 4, UP, EPI><<<grid, block, 0, s>>>(a);
-    HIP_OK(hipGetLastError());
-    return 0;
-}
-
 // finalize + apply BN backward for block li (its g buffer holds masked gradients, stat_part the partials)
 int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s) {
     const Layer& l = h->plan.L[li];
@@ -466,6 +499,11 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     hb.z = last.z; hb.bn = last.bn; hb.w = h->params + hd.w_off; hb.bias = h->params + hd.b_off;
     hb.labels = labels; hb.bc = h->dice_bc; hb.dlogits = h->dlogits; hb.g = last.g; hb.part = h->stat_part;
     hb.HW = hd.H * hd.W; hb.nblk = cdiv(hb.HW, kBlock); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale;
+    {   // backward-data weights of every block for this step's parameters (one launch)
+        ProfScope ps(s, "prep_wt_k", "all", 0, (double)h->wt_total * 8);
+        prep_wt_k<<<std::min<unsigned>((h->wt_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wt_descs, h->n_wt, h->wt_total);
+        HIP_OK(hipGetLastError());
+    }
     int rc = DISPATCH_C(launch_head_bwd, h->cfg.n_cls, hb, hd.cin, B, s);
     if (rc) return rc;
     int pending_nblk = B * hb.nblk;           // number of stat partial rows waiting for block (li-1)
@@ -480,27 +518,33 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s);
         if (rc) return rc;
         if (l.src == SRC_INPUT) break;
-        ConvBwdDataArgs a{};
-        a.dz = l.g; a.w = h->params + l.w_off; a.Cin_total = l.cin; a.Cout = l.cout; a.H = l.H; a.W = l.W;
-        a.drop = make_drop(h); a.accumulate = 0;
-        auto set_out = [&](float* g, int Cg, int ci_off, int Hg, int Wg, const Layer* prod) {
-            a.g = g; a.Cg = Cg; a.ci_off = ci_off; a.Hg = Hg; a.Wg = Wg;
-            a.tiles_x = cdiv(Wg, kTileX); a.tiles = tiles_of(Hg, Wg);
-            a.zin = prod ? prod->z : nullptr; a.bnin = prod ? prod->bn : nullptr; a.part = h->stat_part;
+        // backward-data through the MFMA implicit-GEMM kernel: dz (plain) x transposed / effective weights
+        auto dx = [&](float* gout, int Cg, int ci_off, const Layer* prod, bool up) -> int {
+            IgemmArgs g{};
+            g.x0 = l.g; g.C0 = l.cout; g.flags = 0; g.Cin = l.cout;
+            g.w = l.wt; g.w_ld = l.cin; g.m_off = ci_off; g.out = gout; g.Mout = Cg;
+            g.Hi = l.H; g.Wi = l.W; g.Ho = up ? l.H / 2 : l.H; g.Wo = up ? l.W / 2 : l.W;
+            g.part = prod ? h->stat_part : nullptr; g.zin = prod ? prod->z : nullptr; g.bnin = prod ? prod->bn : nullptr;
+            g.drop_out = (up && l.drop_in) ? 1 : 0; g.drop = make_drop(h);
+            const double px = (double)B * l.H * l.W, pxg = (double)B * g.Ho * g.Wo;
+            const double fl = 2.0 * l.kh * l.kw * Cg * l.cout * px;          // algorithmic flops of the original conv's dX
+            const double by = px * l.cout * 4 + pxg * Cg * 4 * (prod ? 2 : 1);
+            if (up) return launch_igemm<3, A_DOWN2, EPI_MASK>(g, B, s, l.name, fl, by);
+            return prod ? launch_igemm<3, A_NORMAL, EPI_MASK>(g, B, s, l.name, fl, by)
+                        : launch_igemm<3, A_NORMAL, EPI_RAW>(g, B, s, l.name, fl, by);
         };
         switch (l.src) {
             case SRC_PREV: {
                 Layer& p = pl.L[li - 1];
-                set_out(p.g, p.cout, 0, l.H, l.W, &p);
-                rc = launch_dx<3, false, E_MASK>(a, B, s, l.name);
-                pending_nblk = B * a.tiles;
+                const int t = dx(p.g, p.cout, 0, &p, false);
+                if (t < 0) return t;
+                pending_nblk = B * t;
                 break;
             }
             case SRC_POOL: {  // gradient wrt the pooled tensor (raw), then route through the pool into block li-1
                 Layer& p = pl.L[li - 1];
-                set_out(h->gpooled[l.level - 1], l.cin, 0, l.H, l.W, nullptr);
-                rc = launch_dx<3, false, E_RAW>(a, B, s, l.name);
-                if (rc) return rc;
+                const int t = dx(h->gpooled[l.level - 1], l.cin, 0, nullptr, false);
+                if (t < 0) return t;
                 PoolBwdArgs pb{};
                 pb.gp = h->gpooled[l.level - 1]; pb.z = p.z; pb.bn = p.bn; pb.g = p.g; pb.part = h->stat_part;
                 pb.H = p.H; pb.W = p.W; pb.C = p.cout; pb.tiles_x = cdiv(p.W / 2, kTileX); pb.tiles = tiles_of(p.H / 2, p.W / 2);
@@ -514,21 +558,20 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             }
             case SRC_UP: {
                 Layer& p = pl.L[li - 1];
-                set_out(p.g, p.cout, 0, l.H / 2, l.W / 2, &p);
-                rc = l.drop_in ? launch_dx<2, true, E_MASK_DROP>(a, B, s, l.name) : launch_dx<2, true, E_MASK>(a, B, s, l.name);
-                pending_nblk = B * a.tiles;
+                const int t = dx(p.g, p.cout, 0, &p, true);
+                if (t < 0) return t;
+                pending_nblk = B * t;
                 break;
             }
             case SRC_CONCAT: {
                 Layer& p = pl.L[li - 1]; Layer& k = pl.L[l.skip_from];
                 // skip half first (raw, merged later by pool_bwd of that encoder level) ...
-                set_out(k.g, k.cout, p.cout, l.H, l.W, nullptr);
-                rc = launch_dx<3, false, E_RAW>(a, B, s, l.name);
-                if (rc) return rc;
+                int t = dx(k.g, k.cout, p.cout, nullptr, false);
+                if (t < 0) return t;
                 // ... then the up-path half, whose statistics must be the ones pending for block li-1
-                set_out(p.g, p.cout, 0, l.H, l.W, &p);
-                rc = launch_dx<3, false, E_MASK>(a, B, s, l.name);
-                pending_nblk = B * a.tiles;
+                t = dx(p.g, p.cout, 0, &p, false);
+                if (t < 0) return t;
+                pending_nblk = B * t;
                 break;
             }
             default: return fail(-3, "backward: bad src");
@@ -598,6 +641,19 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
         delete h; return fail(-1, "buffers must be aligned (workspace 256 B, params/grads/state 16 B)");
     }
     carve(*c, h->plan, h, (char*)ws);
+    if (c->training) {
+        std::vector<WtDesc> d;
+        unsigned off = 0;
+        for (auto& l : h->plan.L) {
+            if (!l.wt) continue;
+            WtDesc w{}; w.w = params + l.w_off; w.wt = l.wt; w.kh = l.kh; w.cin = l.cin; w.cout = l.cout;
+            w.mode = l.kh == 3 ? 0 : 1; w.start = off; w.count = 9u * l.cin * l.cout;
+            off += w.count; d.push_back(w);
+        }
+        h->n_wt = (int)d.size(); h->wt_total = off;
+        hipError_t e = hipMemcpy(h->wt_descs, d.data(), d.size() * sizeof(WtDesc), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { delete h; return fail(-5, std::string("hipMemcpy(wt_descs): ") + hipGetErrorString(e)); }
+    }
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_u8_lut), lut, sizeof lut);
