@@ -1,0 +1,219 @@
+// MFMA backward-weights kernels:  dW[tap][ci][co] = sum_pixels  X(pixel + tap)[ci] * dz(pixel)[co]
+//   MFMA rows (M) = input channels (or flattened (tap, ci) for thin layers), cols (N) = output channels,
+//   K = pixels.  Both operands are staged NHWC in LDS (channel fastest), which is exactly the operand order the
+//   f32 MFMA wants: 32 (16) consecutive lanes read 32 (16) consecutive floats -> conflict-free ds_read_b32.
+// Each block walks a strided set of pixel tiles accumulating in registers and writes ONE partial
+// [tap][ci][co](+bias) slab; reduce_partials_k sums the slabs in a fixed order (deterministic, no atomics).
+#pragma once
+#include "common.hpp"
+#include "kernels_bwd.hpp"
+#include "kernels_igemm.hpp"
+
+namespace oct {
+
+// float4 fetch of 4 consecutive channels of the conv's logical input (concat / affine / dropout / upsample aware)
+__device__ __forceinline__ float4 fetch_x4(const ConvBwdWArgs& A, size_t pix, int c) {
+    const float* src = reinterpret_cast<const float*>(A.x0); const float* ab = A.ab0; int C = A.C0, cc = c;
+    if ((A.flags & F_TWO) && c >= A.C0) { src = A.x1; ab = A.ab1; C = A.C1; cc = c - A.C0; }
+    float4 v = ld4(src + pix * C + cc);
+    if (A.flags & F_AFF) {
+        const float4 a = ld4(ab + cc), bb = ld4(ab + C + cc);
+        v.x = fmaxf(fmaf(a.x, v.x, bb.x), 0.f); v.y = fmaxf(fmaf(a.y, v.y, bb.y), 0.f);
+        v.z = fmaxf(fmaf(a.z, v.z, bb.z), 0.f); v.w = fmaxf(fmaf(a.w, v.w, bb.w), 0.f);
+    }
+    if (A.flags & F_DROP) {
+        const uint32_t el = (uint32_t)(pix * C + cc);
+        v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
+        v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
+    }
+    return v;
+}
+
+// stage the X tile (with halo; low-res tile for an up-conv) NHWC into LDS
+template <int CIC, int IH, int IW, bool UP, int KH, int TH>
+__device__ __forceinline__ void stage_x(const ConvBwdWArgs& A, float* Xs, int b, int y0, int x0, int ci0) {
+    const int Hs = UP ? A.H >> 1 : A.H, Ws = UP ? A.W >> 1 : A.W;
+    const int iy0 = UP ? y0 / 2 : y0 - (KH - 1) / 2, ix0 = UP ? x0 / 2 : x0 - (KH - 1) / 2;
+    for (int e = threadIdx.x; e < IH * IW * (CIC / 4); e += kBlock) {
+        const int q = e % (CIC / 4), p = e / (CIC / 4), lx = p % IW, ly = p / IW;
+        const int gy = iy0 + ly, gx = ix0 + lx, c = ci0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < Hs && gx >= 0 && gx < Ws && c < A.Cin) v = fetch_x4(A, ((size_t)b * Hs + gy) * Ws + gx, c);
+        st4(Xs + (ly * IW + lx) * CIC + 4 * q, v);
+    }
+}
+
+// stage the dz tile [TH][32][COC]; returns this thread's running column sums (its channel quad is fixed)
+template <int COC, int TH>
+__device__ __forceinline__ void stage_dz(const ConvBwdWArgs& A, float* Ds, int b, int y0, int x0, int co0, float4& bsum) {
+    for (int e = threadIdx.x; e < TH * 32 * (COC / 4); e += kBlock) {
+        const int q = e % (COC / 4), p = e / (COC / 4), px = p % 32, py = p / 32;
+        const int oy = y0 + py, ox = x0 + px, c = co0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oy < A.H && ox < A.W && c < A.Cout) v = ld4(A.dz + (((size_t)b * A.H + oy) * A.W + ox) * A.Cout + c);
+        st4(Ds + p * COC + 4 * q, v);
+        bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+    }
+}
+
+// bias gradient = column sums of dz: reduce the per-thread quads through LDS (threads with equal tid % (COC/4) share a quad)
+template <int COC>
+__device__ __forceinline__ void bias_reduce(const ConvBwdWArgs& A, float* scratch /*>= 1024 floats*/, const float4& bsum,
+                                   float* out_bias, int co0, bool write) {
+    __syncthreads();
+    st4(scratch + threadIdx.x * 4, bsum);
+    __syncthreads();
+    if ((int)threadIdx.x < COC) {
+        const int quad = threadIdx.x / 4, comp = threadIdx.x % 4;
+        float s = 0.f;
+        for (int t = quad; t < kBlock; t += COC / 4) s += scratch[t * 4 + comp];
+        if (write && co0 + (int)threadIdx.x < A.Cout) out_bias[co0 + threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// thin layers: v_mfma_f32_16x16x4_f32, M = flattened (tap, ci) rows in tiles of 16, N = 16 output channels.
+// Every wave owns ALL M tiles for a quarter of the tile's pixel rows; 4-wave sum through LDS at the end.
+// grid (npb, ceil(Cin/CIC), ceil(Cout/16))
+// ---------------------------------------------------------------------------------------------------------------
+template <int KH, int CIC, bool UP>
+__global__ __launch_bounds__(kBlock) void conv_dw16_k(const ConvBwdWArgs A) {
+    constexpr int TH = 8, TW = 32, TAPS = KH * KH, MROWS = TAPS * CIC, MTILES = (MROWS + 15) / 16;
+    constexpr int IH = UP ? TH / 2 + 1 : TH + KH - 1, IW = UP ? TW / 2 + 1 : TW + KH - 1;
+    constexpr int XS = IH * IW * CIC, DS = TH * TW * 16, RED = 4 * MTILES * 256;
+    constexpr int LDSN = (XS + DS > RED ? XS + DS : RED) > 1024 ? (XS + DS > RED ? XS + DS : RED) : 1024;
+    __shared__ float lds[LDSN];
+    float* Xs = lds; float* Ds = lds + XS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
+    const int ci0 = blockIdx.y * CIC, co0 = blockIdx.z * 16;
+
+    int aoff[MTILES], aky[MTILES], akx[MTILES], aci[MTILES]; bool aval[MTILES];
+#pragma unroll
+    for (int mt = 0; mt < MTILES; ++mt) {
+        const int mrow = mt * 16 + i, tap = mrow / CIC;
+        aval[mt] = mrow < MROWS; aci[mt] = mrow % CIC; aky[mt] = tap / KH; akx[mt] = tap % KH;
+        aoff[mt] = (aky[mt] * IW + akx[mt]) * CIC + aci[mt];
+    }
+    f32x4 acc[MTILES];
+#pragma unroll
+    for (int mt = 0; mt < MTILES; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int tl = blockIdx.x; tl < A.total_tiles; tl += A.npb) {
+        const int b = tl / A.tiles, tile = tl % A.tiles;
+        const int x0 = (tile % A.tiles_x) * TW, y0 = (tile / A.tiles_x) * TH;
+        __syncthreads();
+        stage_x<CIC, IH, IW, UP, KH, TH>(A, Xs, b, y0, x0, ci0);
+        stage_dz<16, TH>(A, Ds, b, y0, x0, co0, bsum);
+        __syncthreads();
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs) {
+            const int rr = wave + 4 * rs;
+#pragma unroll 2
+            for (int ks = 0; ks < TW / 4; ++ks) {
+                const int p = 4 * ks + kk;
+                const float bv = Ds[(rr * TW + p) * 16 + i];
+#pragma unroll
+                for (int mt = 0; mt < MTILES; ++mt) {
+                    int off;
+                    if constexpr (UP) off = (((rr + aky[mt]) >> 1) * IW + ((p + akx[mt]) >> 1)) * CIC + aci[mt];
+                    else off = aoff[mt] + (rr * IW + p) * CIC;
+                    const float a = aval[mt] ? Xs[off] : 0.f;
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- 4-wave sum through LDS, then the slab ----
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MTILES; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[(wave * MTILES + mt) * 256 + r * 64 + lane] = acc[mt][r];
+    __syncthreads();
+    const size_t wsize = (size_t)TAPS * A.Cin * A.Cout;
+    float* out = A.part + (size_t)blockIdx.x * (wsize + A.Cout);
+    for (int idx = tid; idx < MTILES * 256; idx += kBlock) {
+        const int mt = idx / 256, rem = idx % 256, r = rem / 64, ln = rem % 64;
+        const float s = (lds[(0 * MTILES + mt) * 256 + rem] + lds[(1 * MTILES + mt) * 256 + rem]) +
+                        (lds[(2 * MTILES + mt) * 256 + rem] + lds[(3 * MTILES + mt) * 256 + rem]);
+        const int col = ln & 15, row = 4 * (ln >> 4) + r, mrow = mt * 16 + row;
+        const int tap = mrow / CIC, ci = mrow % CIC;
+        if (mrow < MROWS && ci0 + ci < A.Cin && co0 + col < A.Cout)
+            out[((size_t)tap * A.Cin + ci0 + ci) * A.Cout + co0 + col] = s;
+    }
+    bias_reduce<16>(A, lds, bsum, out + wsize, co0, blockIdx.y == 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wide layers: v_mfma_f32_32x32x2_f32, block = CIC (32|64) input channels x 32 output channels x all taps.
+// The (ci-tile, tap) units are dealt round-robin to the 4 waves; every wave sweeps all pixels of the tile for
+// its own units, so no cross-wave reduction is needed.   grid (npb, Cin/CIC, Cout/32)
+// ---------------------------------------------------------------------------------------------------------------
+template <int KH, int CIC, bool UP, int TH>
+__global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
+    constexpr int TW = 32, COC = 32, TAPS = KH * KH, MTB = CIC / 32, UNITS = MTB * TAPS, UPW = (UNITS + 3) / 4;
+    constexpr int IH = UP ? TH / 2 + 1 : TH + KH - 1, IW = UP ? TW / 2 + 1 : TW + KH - 1;
+    constexpr int XS = IH * IW * CIC, DS = TH * TW * COC;
+    __shared__ float lds[(XS + DS) > 1024 ? (XS + DS) : 1024];
+    float* Xs = lds; float* Ds = lds + XS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, kk = lane >> 5;
+    const int ci0 = blockIdx.y * CIC, co0 = blockIdx.z * COC;
+
+    int uky[UPW], ukx[UPW], umt[UPW];
+#pragma unroll
+    for (int k = 0; k < UPW; ++k) {
+        const int u = wave + 4 * k, tap = u / MTB;
+        umt[k] = u % MTB; uky[k] = tap / KH; ukx[k] = tap % KH;
+    }
+    f32x16 acc[UPW];
+#pragma unroll
+    for (int k = 0; k < UPW; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int tl = blockIdx.x; tl < A.total_tiles; tl += A.npb) {
+        const int b = tl / A.tiles, tile = tl % A.tiles;
+        const int x0 = (tile % A.tiles_x) * TW, y0 = (tile / A.tiles_x) * TH;
+        __syncthreads();
+        stage_x<CIC, IH, IW, UP, KH, TH>(A, Xs, b, y0, x0, ci0);
+        stage_dz<COC, TH>(A, Ds, b, y0, x0, co0, bsum);
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < TH; ++rr) {
+#pragma unroll 2
+            for (int ks = 0; ks < TW / 2; ++ks) {
+                const int p = 2 * ks + kk;
+                const float bv = Ds[(rr * TW + p) * COC + i];
+#pragma unroll
+                for (int k = 0; k < UPW; ++k) {
+                    if (wave + 4 * k < UNITS) {   // wave-uniform
+                        int off;
+                        if constexpr (UP) off = (((rr + uky[k]) >> 1) * IW + ((p + ukx[k]) >> 1)) * CIC + umt[k] * 32 + i;
+                        else off = ((rr + uky[k]) * IW + p + ukx[k]) * CIC + umt[k] * 32 + i;
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[off], bv, acc[k], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    const size_t wsize = (size_t)TAPS * A.Cin * A.Cout;
+    float* out = A.part + (size_t)blockIdx.x * (wsize + A.Cout);
+#pragma unroll
+    for (int k = 0; k < UPW; ++k) {
+        const int u = wave + 4 * k;
+        if (u < UNITS) {
+            const int tap = u / MTB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;    // D: row = ci within the 32-tile, col = co
+                const int ci = ci0 + umt[k] * 32 + row, co = co0 + i;
+                if (ci < A.Cin && co < A.Cout) out[((size_t)tap * A.Cin + ci) * A.Cout + co] = acc[k][r];
+            }
+        }
+    }
+    bias_reduce<COC>(A, lds, bsum, out + wsize, co0, blockIdx.y == 0);
+}
+
+}  // namespace oct

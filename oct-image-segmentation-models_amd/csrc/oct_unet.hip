@@ -13,6 +13,7 @@
 #include "kernels_bwd.hpp"
 #include "kernels_fwd.hpp"
 #include "kernels_igemm.hpp"
+#include "kernels_dw.hpp"
 
 using namespace oct;
 
@@ -140,16 +141,23 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int tiles_of(int H, int W) { return cdiv(H, kTileY) * cdiv(W, kTileX); }
 inline int chunk_of(int c) { return c % 16 == 0 ? 16 : (c % 8 == 0 ? 8 : 4); }   // channel chunk per thread
 
-// dW pixel-block count: enough blocks to fill 256 CUs a few times over, never more than the tile count
-int dw_npb(const Layer& l, int B, int ci_t, int co_t) {
-    const int chunks = cdiv(l.cin, ci_t) * cdiv(l.cout, co_t);
-    const int total = B * tiles_of(l.H, l.W);
-    int npb = cdiv(1024, chunks);
-    if (npb > total) npb = total;
-    return npb < 1 ? 1 : npb;
+// dW plan: which kernel handles a layer, its channel chunking, pixel-tile height and pixel-block count
+struct DwPlan { int kind;  /* 0 = VALU (1-channel input / head), 16, 32 */ int cic, coc, th, chunks, npb, tiles; };
+DwPlan dw_plan(const Layer& l, int B) {
+    DwPlan p{};
+    if (l.cin % 4 || l.cout % 4 || l.kh == 1) {   // first layer (in_ch not a multiple of 4) and the 1x1 n_cls-wide head
+        p.kind = 0; p.cic = l.cin % 4 ? 1 : chunk_of(l.cin); p.coc = l.cout % 4 ? (l.cout <= 4 ? 4 : 8) : chunk_of(l.cout); p.th = kTileY;
+    } else if (l.cin >= 32 && l.cout >= 32) {
+        p.kind = 32; p.cic = l.cin % 64 == 0 ? 64 : 32; p.coc = 32; p.th = p.cic == 64 ? 2 : 4;
+    } else {
+        p.kind = 16; p.cic = l.cin >= 16 ? 16 : 8; p.coc = 16; p.th = 8;
+    }
+    p.chunks = cdiv(l.cin, p.cic) * cdiv(l.cout, p.coc);
+    p.tiles = cdiv(l.H, p.th) * cdiv(l.W, kTileX);
+    const int total = B * p.tiles;
+    p.npb = std::max(1, std::min(total, cdiv(1024, p.chunks)));
+    return p;
 }
-inline int dw_ci_t(const Layer& l) { return l.cin % 4 ? 1 : chunk_of(l.cin); }
-inline int dw_co_t(const Layer& l) { return l.cout % 4 ? (l.cout <= 4 ? 4 : 8) : chunk_of(l.cout); }
 
 }  // namespace
 
@@ -189,7 +197,7 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
         stat_max = std::max(stat_max, B * cdiv(l.H, 2) * cdiv(l.W, kTileX) * 2 * (size_t)std::max(l.cout, l.cin));
         if (c.training) {
             const size_t wsz = (size_t)l.kh * l.kw * l.cin * l.cout + l.cout;
-            dw_max = std::max(dw_max, (size_t)dw_npb(l, c.max_batch, dw_ci_t(l), dw_co_t(l)) * wsz);
+            dw_max = std::max(dw_max, (size_t)dw_plan(l, c.max_batch).npb * wsz);
         }
     }
     for (int i = 0; i < pl.P; ++i) {
@@ -438,9 +446,7 @@ int launch_dw(const ConvBwdWArgs& a, int ci_t, int co_t, hipStream_t s, const ch
     ProfScope ps(s, nm, layer, flops, bytes);
 #define DW_CASE(CI, CO) if (ci_t == CI && co_t == CO) { conv_bwd_w_k<KH, CI, CO><<<grid, block, 0, s>>>(a); HIP_OK(hipGetLastError()); return 0; }
     DW_CASE(1, 4) DW_CASE(1, 8) DW_CASE(1, 16)
-    DW_CASE(4, 4) DW_CASE(4, 8) DW_CASE(4, 16)
-    DW_CASE(8, 4) DW_CASE(8, 8) DW_CASE(8, 16)
-    DW_CASE(16, 4) DW_CASE(16, 8) DW_CASE(16, 16)
+    DW_CASE(4, 4) DW_CASE(4, 8) DW_CASE(8, 4) DW_CASE(8, 8) DW_CASE(16, 4) DW_CASE(16, 8)
 #undef DW_CASE
     return fail(-3, "dW: unsupported channel chunking");
 }
@@ -448,28 +454,41 @@ int launch_dw(const ConvBwdWArgs& a, int ci_t, int co_t, hipStream_t s, const ch
 int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const float* dz, int B, hipStream_t s) {
     const Layer& l = h->plan.L[li];
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
+    const DwPlan p = dw_plan(l, B);
     ConvBwdWArgs a{};
     a.x0 = sd.x0; a.ab0 = sd.ab0; a.C0 = sd.C0; a.x1 = sd.x1; a.ab1 = sd.ab1; a.C1 = sd.C1;
     a.flags = sd.flags | (l.drop_in ? F_DROP : 0);
     a.dz = dz; a.part = h->dw_part;
     a.B = B; a.H = l.H; a.W = l.W; a.Cin = l.cin; a.Cout = l.cout;
-    a.tiles_x = cdiv(l.W, kTileX); a.tiles = tiles_of(l.H, l.W); a.total_tiles = B * a.tiles;
-    const int ci_t = dw_ci_t(l), co_t = dw_co_t(l);
-    a.npb = dw_npb(l, B, ci_t, co_t);
+    a.tiles_x = cdiv(l.W, kTileX); a.tiles = p.tiles; a.total_tiles = B * a.tiles; a.npb = p.npb;
     a.drop = make_drop(h);
     const double px = (double)B * l.H * l.W, fl = 2.0 * l.kh * l.kw * l.cin * l.cout * px;
     const double by = in_bytes(l, B, x_is_u8) + px * l.cout * 4;   // conv input once + dz once
-    int rc;
-    switch (l.kh) {
-        case 1: rc = launch_dw<1>(a, ci_t, co_t, s, l.name, fl, by); break;
-        case 2: rc = launch_dw<2>(a, ci_t, co_t, s, l.name, fl, by); break;
-        default: rc = launch_dw<3>(a, ci_t, co_t, s, l.name, fl, by); break;
+    const bool up = l.src == SRC_UP;
+    int rc = 0;
+    if (p.kind == 0) {
+        switch (l.kh) {
+            case 1: rc = launch_dw<1>(a, p.cic, p.coc, s, l.name, fl, by); break;
+            default: rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by); break;
+        }
+    } else {
+        dim3 grid(p.npb, cdiv(l.cin, p.cic), cdiv(l.cout, p.coc)), block(kBlock);
+        char nm[48]; snprintf(nm, sizeof nm, "conv_dw%d_k<%d,%d,%d>", p.kind, l.kh, p.cic, (int)up);
+        ProfScope ps(s, nm, l.name, fl, by);
+        if (p.kind == 16) {
+            if (up) { if (p.cic == 16) conv_dw16_k<2, 16, true><<<grid, block, 0, s>>>(a); else conv_dw16_k<2, 8, true><<<grid, block, 0, s>>>(a); }
+            else { if (p.cic == 16) conv_dw16_k<3, 16, false><<<grid, block, 0, s>>>(a); else conv_dw16_k<3, 8, false><<<grid, block, 0, s>>>(a); }
+        } else {
+            if (up) { if (p.cic == 64) conv_dw32_k<2, 64, true, 2><<<grid, block, 0, s>>>(a); else conv_dw32_k<2, 32, true, 4><<<grid, block, 0, s>>>(a); }
+            else { if (p.cic == 64) conv_dw32_k<3, 64, false, 2><<<grid, block, 0, s>>>(a); else conv_dw32_k<3, 32, false, 4><<<grid, block, 0, s>>>(a); }
+        }
+        HIP_OK(hipGetLastError());
     }
     if (rc) return rc;
     const size_t wsize = (size_t)l.kh * l.kw * l.cin * l.cout, stride = wsize + l.cout;
     ProfScope ps(s, "reduce_partials_k", l.name, 0, (double)a.npb * stride * 4);
     reduce_partials_k<<<(int)((stride + 63) / 64), kBlock, 0, s>>>(h->dw_part, a.npb, stride, wsize,
-                                                                              h->grads + l.w_off, h->grads + l.b_off);
+                                                                  h->grads + l.w_off, h->grads + l.b_off);
     HIP_OK(hipGetLastError());
     return 0;
 }
