@@ -379,20 +379,24 @@ __global__ __launch_bounds__(kBlock) void conv_bwd_w_k(const ConvBwdWArgs A) {
     }
 }
 
-// second stage: grads[j] = sum over pixel blocks of part[pb][j].  Block = 64 consecutive j x 4 slices of pb;
-// fixed summation order (deterministic), double accumulation.
+// second stage: grads[j] = sum over pixel blocks of part[pb][j].  Block = JW consecutive j x (256/JW) slices of
+// pb; fixed summation order (deterministic), double accumulation.
+template <int JW>
 __global__ __launch_bounds__(kBlock) void reduce_partials_k(const float* __restrict__ part, int npb, size_t stride,
                                                            size_t wsize, float* __restrict__ dw, float* __restrict__ db) {
-    __shared__ double sh[4][64];
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const size_t j = (size_t)blockIdx.x * 64 + lane;
+    constexpr int NQ = kBlock / JW;
+    __shared__ double sh[NQ][JW];
+    const int col = threadIdx.x % JW, q = threadIdx.x / JW;
+    const size_t j = (size_t)blockIdx.x * JW + col;
     double s = 0;
     if (j < stride)
-        for (int p = q; p < npb; p += 4) s += part[(size_t)p * stride + j];
-    sh[q][lane] = s;
+        for (int p = q; p < npb; p += NQ) s += part[(size_t)p * stride + j];
+    sh[q][col] = s;
     __syncthreads();
     if (q == 0 && j < stride) {
-        const double t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) t += sh[k][col];
         if (j < wsize) dw[j] = (float)t; else db[j - wsize] = (float)t;
     }
 }

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
             st4(Ws + (tap * KC + kc) * MB + 4 * m4, v);
         }
         __syncthreads();
-        // ---- MFMA over taps x k-steps ----
+        // ---- MFMA over taps x k-steps (only the channels that exist: thin layers have Cin < KC) ----
+        const int nks = (A.Cin - c0 < KC ? A.Cin - c0 : KC) / KS;
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) {
 #pragma unroll
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
                     }
                 }
 #pragma unroll 2
-                for (int ks = 0; ks < KC / KS; ++ks) {
+                for (int ks = 0; ks < nks; ++ks) {
                     const int kc = ks * KS + kk;
                     float a[MTW], bv[NTW];
 #pragma unroll

@@ -155,7 +155,7 @@ DwPlan dw_plan(const Layer& l, int B) {
     p.chunks = cdiv(l.cin, p.cic) * cdiv(l.cout, p.coc);
     p.tiles = cdiv(l.H, p.th) * cdiv(l.W, kTileX);
     const int total = B * p.tiles;
-    p.npb = std::max(1, std::min(total, cdiv(1024, p.chunks)));
+    p.npb = std::max(1, std::min(total, cdiv(768, p.chunks)));
     return p;
 }
 
@@ -487,8 +487,10 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const fl
     if (rc) return rc;
     const size_t wsize = (size_t)l.kh * l.kw * l.cin * l.cout, stride = wsize + l.cout;
     ProfScope ps(s, "reduce_partials_k", l.name, 0, (double)a.npb * stride * 4);
-    reduce_partials_k<<<(int)((stride + 63) / 64), kBlock, 0, s>>>(h->dw_part, a.npb, stride, wsize,
-                                                                  h->grads + l.w_off, h->grads + l.b_off);
+    if (stride < 16384)   // small slabs: 16 columns x 16 slab slices per block, so the sum is parallel over slabs too
+        reduce_partials_k<16><<<(int)((stride + 15) / 16), kBlock, 0, s>>>(h->dw_part, a.npb, stride, wsize, h->grads + l.w_off, h->grads + l.b_off);
+    else
+        reduce_partials_k<64><<<(int)((stride + 63) / 64), kBlock, 0, s>>>(h->dw_part, a.npb, stride, wsize, h->grads + l.w_off, h->grads + l.b_off);
     HIP_OK(hipGetLastError());
     return 0;
 }
