@@ -130,6 +130,11 @@ typedef struct oct_profile_entry {
 int oct_unet_profile_begin(oct_unet* h);
 int oct_unet_profile_end(oct_unet* h, oct_profile_entry* out, int max_entries, int* n_out);
 
+/* ---- tuning knobs (process-wide; results do not depend on them, only which kernel variant runs) ----
+ *   "igemm_persistent_min_tiles" (default 2048): number of pixel tiles from which thin single-chunk convs use the
+ *   persistent software-pipelined kernel instead of the one-tile-per-block kernel. */
+int oct_set_option(const char* name, int value);
+
 /* ---- introspection for tests: device pointer of a layer's saved pre-BN output / gradient ---- */
 const float* oct_unet_debug_activation(oct_unet* h, int layer, int which /*0=z,1=g*/);
 

@@ -11,11 +11,18 @@
 
 namespace oct {
 
-// float4 fetch of 4 consecutive channels of the conv's logical input (concat / affine / dropout / upsample aware)
-__device__ __forceinline__ float4 fetch_x4(const ConvBwdWArgs& A, size_t pix, int c) {
-    const float* src = reinterpret_cast<const float*>(A.x0); const float* ab = A.ab0; int C = A.C0, cc = c;
-    if ((A.flags & F_TWO) && c >= A.C0) { src = A.x1; ab = A.ab1; C = A.C1; cc = c - A.C0; }
-    float4 v = ld4(src + pix * C + cc);
+// ---- software-pipelined staging: the global loads of tile t+1 are issued (into registers) before the MFMA loop of
+// tile t and written to LDS (with the consumer-side transform) after it, so HBM/L2 latency hides under compute ----
+
+// address part of the logical-input fetch: pointer to 4 consecutive channels (concat aware)
+__device__ __forceinline__ const float* x4_ptr(const ConvBwdWArgs& A, size_t pix, int c) {
+    if ((A.flags & F_TWO) && c >= A.C0) return A.x1 + pix * A.C1 + (c - A.C0);
+    return reinterpret_cast<const float*>(A.x0) + pix * A.C0 + c;
+}
+// transform part: BN+ReLU affine and dropout of the 4 loaded channels
+__device__ __forceinline__ float4 x4_xform(const ConvBwdWArgs& A, float4 v, size_t pix, int c) {
+    const float* ab = A.ab0; int C = A.C0, cc = c;
+    if ((A.flags & F_TWO) && c >= A.C0) { ab = A.ab1; C = A.C1; cc = c - A.C0; }
     if (A.flags & F_AFF) {
         const float4 a = ld4(ab + cc), bb = ld4(ab + C + cc);
         v.x = fmaxf(fmaf(a.x, v.x, bb.x), 0.f); v.y = fmaxf(fmaf(a.y, v.y, bb.y), 0.f);
@@ -29,32 +36,62 @@ __device__ __forceinline__ float4 fetch_x4(const ConvBwdWArgs& A, size_t pix, in
     return v;
 }
 
-// stage the X tile (with halo; low-res tile for an up-conv) NHWC into LDS
-template <int CIC, int IH, int IW, bool UP, int KH, int TH>
-__device__ __forceinline__ void stage_x(const ConvBwdWArgs& A, float* Xs, int b, int y0, int x0, int ci0) {
-    const int Hs = UP ? A.H >> 1 : A.H, Ws = UP ? A.W >> 1 : A.W;
-    const int iy0 = UP ? y0 / 2 : y0 - (KH - 1) / 2, ix0 = UP ? x0 / 2 : x0 - (KH - 1) / 2;
-    for (int e = threadIdx.x; e < IH * IW * (CIC / 4); e += kBlock) {
-        const int q = e % (CIC / 4), p = e / (CIC / 4), lx = p % IW, ly = p / IW;
-        const int gy = iy0 + ly, gx = ix0 + lx, c = ci0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < Hs && gx >= 0 && gx < Ws && c < A.Cin) v = fetch_x4(A, ((size_t)b * Hs + gy) * Ws + gx, c);
-        st4(Xs + (ly * IW + lx) * CIC + 4 * q, v);
-    }
-}
+template <int CIC, int COC, int IH, int IW, bool UP, int KH, int TH>
+struct TileStager {
+    static constexpr int NX = (IH * IW * (CIC / 4) + kBlock - 1) / kBlock;   // float4 per thread, X tile
+    static constexpr int ND = (TH * 32 * (COC / 4) + kBlock - 1) / kBlock;   // float4 per thread, dz tile
+    float4 xr[NX], dr[ND];
 
-// stage the dz tile [TH][32][COC]; returns this thread's running column sums (its channel quad is fixed)
-template <int COC, int TH>
-__device__ __forceinline__ void stage_dz(const ConvBwdWArgs& A, float* Ds, int b, int y0, int x0, int co0, float4& bsum) {
-    for (int e = threadIdx.x; e < TH * 32 * (COC / 4); e += kBlock) {
-        const int q = e % (COC / 4), p = e / (COC / 4), px = p % 32, py = p / 32;
-        const int oy = y0 + py, ox = x0 + px, c = co0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (oy < A.H && ox < A.W && c < A.Cout) v = ld4(A.dz + (((size_t)b * A.H + oy) * A.W + ox) * A.Cout + c);
-        st4(Ds + p * COC + 4 * q, v);
-        bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+    // issue the global loads of tile (b, y0, x0); out-of-range elements load nothing and become zeros
+    __device__ __forceinline__ void load(const ConvBwdWArgs& A, int b, int y0, int x0, int ci0, int co0) {
+        const int Hs = UP ? A.H >> 1 : A.H, Ws = UP ? A.W >> 1 : A.W;
+        const int iy0 = UP ? y0 / 2 : y0 - (KH - 1) / 2, ix0 = UP ? x0 / 2 : x0 - (KH - 1) / 2;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int e = threadIdx.x + k * kBlock;
+            const int q = e % (CIC / 4), p = e / (CIC / 4), lx = p % IW, ly = p / IW;
+            const int gy = iy0 + ly, gx = ix0 + lx, c = ci0 + 4 * q;
+            xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < IH * IW * (CIC / 4) && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws && c < A.Cin)
+                xr[k] = ld4(x4_ptr(A, ((size_t)b * Hs + gy) * Ws + gx, c));
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int e = threadIdx.x + k * kBlock;
+            const int q = e % (COC / 4), p = e / (COC / 4), px = p % 32, py = p / 32;
+            const int oy = y0 + py, ox = x0 + px, c = co0 + 4 * q;
+            dr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < TH * 32 * (COC / 4) && oy < A.H && ox < A.W && c < A.Cout)
+                dr[k] = ld4(A.dz + (((size_t)b * A.H + oy) * A.W + ox) * A.Cout + c);
+        }
     }
-}
+    // write the loaded tile to LDS, applying the input transform; accumulates dz column sums (bias gradient)
+    __device__ __forceinline__ void store(const ConvBwdWArgs& A, float* Xs, float* Ds, int b, int y0, int x0, int ci0,
+                                          float4& bsum) {
+        const int Hs = UP ? A.H >> 1 : A.H, Ws = UP ? A.W >> 1 : A.W;
+        const int iy0 = UP ? y0 / 2 : y0 - (KH - 1) / 2, ix0 = UP ? x0 / 2 : x0 - (KH - 1) / 2;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int e = threadIdx.x + k * kBlock;
+            if (e < IH * IW * (CIC / 4)) {
+                const int q = e % (CIC / 4), p = e / (CIC / 4), lx = p % IW, ly = p / IW;
+                const int gy = iy0 + ly, gx = ix0 + lx, c = ci0 + 4 * q;
+                float4 v = xr[k];
+                if (gy >= 0 && gy < Hs && gx >= 0 && gx < Ws && c < A.Cin)
+                    v = x4_xform(A, v, ((size_t)b * Hs + gy) * Ws + gx, c);   // out-of-range stays exactly zero
+                st4(Xs + (ly * IW + lx) * CIC + 4 * q, v);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int e = threadIdx.x + k * kBlock;
+            if (e < TH * 32 * (COC / 4)) {
+                st4(Ds + (e / (COC / 4)) * COC + 4 * (e % (COC / 4)), dr[k]);
+                bsum.x += dr[k].x; bsum.y += dr[k].y; bsum.z += dr[k].z; bsum.w += dr[k].w;
+            }
+        }
+    }
+};
 
 // bias gradient = column sums of dz: reduce the per-thread quads through LDS (threads with equal tid % (COC/4) share a quad)
 template <int COC>
@@ -99,13 +136,26 @@ __global__ __launch_bounds__(kBlock) void conv_dw16_k(const ConvBwdWArgs A) {
     for (int mt = 0; mt < MTILES; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    TileStager<CIC, 16, IH, IW, UP, KH, TH> st;
+    auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
+        b = tl / A.tiles; const int tile = tl % A.tiles;
+        x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;
+    };
+    {
+        int b, y0, x0;
+        if ((int)blockIdx.x < A.total_tiles) { tile_of(blockIdx.x, b, y0, x0); st.load(A, b, y0, x0, ci0, co0); }
+    }
     for (int tl = blockIdx.x; tl < A.total_tiles; tl += A.npb) {
-        const int b = tl / A.tiles, tile = tl % A.tiles;
-        const int x0 = (tile % A.tiles_x) * TW, y0 = (tile / A.tiles_x) * TH;
+        int b, y0, x0;
+        tile_of(tl, b, y0, x0);
+        __syncthreads();                                   // every wave is done with the previous tile's LDS image
+        st.store(A, Xs, Ds, b, y0, x0, ci0, bsum);
         __syncthreads();
-        stage_x<CIC, IH, IW, UP, KH, TH>(A, Xs, b, y0, x0, ci0);
-        stage_dz<16, TH>(A, Ds, b, y0, x0, co0, bsum);
-        __syncthreads();
+        if (tl + A.npb < A.total_tiles) {                  // next tile's loads fly while this tile computes
+            int nb, ny0, nx0;
+            tile_of(tl + A.npb, nb, ny0, nx0);
+            st.load(A, nb, ny0, nx0, ci0, co0);
+        }
 #pragma unroll
         for (int rs = 0; rs < 2; ++rs) {
             const int rr = wave + 4 * rs;
@@ -173,13 +223,26 @@ __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    TileStager<CIC, COC, IH, IW, UP, KH, TH> st;
+    auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
+        b = tl / A.tiles; const int tile = tl % A.tiles;
+        x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;
+    };
+    {
+        int b, y0, x0;
+        if ((int)blockIdx.x < A.total_tiles) { tile_of(blockIdx.x, b, y0, x0); st.load(A, b, y0, x0, ci0, co0); }
+    }
     for (int tl = blockIdx.x; tl < A.total_tiles; tl += A.npb) {
-        const int b = tl / A.tiles, tile = tl % A.tiles;
-        const int x0 = (tile % A.tiles_x) * TW, y0 = (tile / A.tiles_x) * TH;
+        int b, y0, x0;
+        tile_of(tl, b, y0, x0);
+        __syncthreads();                                   // every wave is done with the previous tile's LDS image
+        st.store(A, Xs, Ds, b, y0, x0, ci0, bsum);
         __syncthreads();
-        stage_x<CIC, IH, IW, UP, KH, TH>(A, Xs, b, y0, x0, ci0);
-        stage_dz<COC, TH>(A, Ds, b, y0, x0, co0, bsum);
-        __syncthreads();
+        if (tl + A.npb < A.total_tiles) {                  // next tile's loads fly while this tile computes
+            int nb, ny0, nx0;
+            tile_of(tl + A.npb, nb, ny0, nx0);
+            st.load(A, nb, ny0, nx0, ci0, co0);
+        }
 #pragma unroll
         for (int rr = 0; rr < TH; ++rr) {
 #pragma unroll 2

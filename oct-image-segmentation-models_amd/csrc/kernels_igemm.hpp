@@ -35,7 +35,7 @@ struct IgemmArgs {
     const float* bias;                           // EPI_FWD
     float* out; int Mout;                        // (B,Ho,Wo,Mout)
     int Ho, Wo, Hi, Wi;                          // output / input-source spatial dims
-    int tiles_x, tiles;
+    int tiles_x, tiles, total_tiles;            // total_tiles = B * tiles (persistent variant)
     float* part;                                 // [B*tiles][2*Mout] statistic partials (EPI_FWD / EPI_MASK) or nullptr
     const float* zin; const float* bnin;         // EPI_MASK: producer's raw output (B,Ho,Wo,Mout) + its BN record
     int drop_out;                                // EPI_MASK: the producer's output passes through dropout
@@ -267,6 +267,253 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
                 for (int w = 0; w < WN; ++w) s += red[(((wmm * WN + w) * 2 + stat) * MTW + mt) * MT + mloc];
                 if (m0 + ml < A.Mout)
                     A.part[((size_t)b * A.tiles + tile) * (2 * A.Mout) + (size_t)stat * A.Mout + m0 + ml] = s;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined variant for single-chunk layers (Cin <= KCP <= 16: the thin full-resolution layers,
+// which are HBM/latency-bound rather than MFMA-bound).  One block walks a strided list of pixel tiles:
+//   * the weight tile is staged ONCE per block;
+//   * the input tile is double-buffered in LDS; the global loads of tile t+1 (and, for EPI_MASK, the producer's z of
+//     tile t) are issued before the MFMA loop of tile t, so their latency hides under compute -- one barrier per tile;
+//   * BN statistics accumulate in registers across all tiles of the block; ONE partial row per block.
+// grid (nblk, ceil(Mout/MB), 1); A.tiles = pixel tiles per image, A.total_tiles = B * A.tiles.
+// ------------------------------------------------------------------------------------------------------------------
+template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN, int KCP>
+__global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
+    using S = MfmaShape<SHAPE>;
+    constexpr int MT = SHAPE, NT = SHAPE, KS = S::KS, ACC = S::ACC, QUADS = S::QUADS;
+    constexpr int TW = 32, NPR = TW / NT, NTB = TH * NPR, MTB = MB / MT, WM = 4 / WN;
+    constexpr int NTW = NTB / WN, MTW = MTB / WM, TAPS = KH * KH;
+    static_assert(NTB % WN == 0 && MTB % WM == 0 && NTW >= 1 && MTW >= 1, "bad wave arrangement");
+    constexpr int IH = AMODE == A_NORMAL ? TH + KH - 1 : (AMODE == A_UPF ? TH / 2 + 1 : 2 * TH + 1);
+    constexpr int IW = AMODE == A_NORMAL ? TW + KH - 1 : (AMODE == A_UPF ? TW / 2 + 1 : 2 * TW + 1);
+    constexpr int PLANE = ((IH * IW + 15) / 32) * 32 + 16;
+    constexpr int NPF = ((KCP / 4) * IH * IW + kBlock - 1) / kBlock;     // prefetched float4 per thread
+    constexpr int RED = 4 * 2 * MTW * MT;
+
+    __shared__ float Is[2][KCP * PLANE];
+    __shared__ float Ws[TAPS * KCP * MB];
+    __shared__ float red[RED];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
+    const int j = lane & (NT - 1), kk = lane / NT, h = kk;
+    const int m0 = blockIdx.y * MB;
+    const int nks = (A.Cin < KCP ? A.Cin : KCP) / KS;
+
+    for (int e = tid; e < TAPS * KCP * (MB / 4); e += kBlock) {          // weights: once per block
+        const int m4 = e % (MB / 4), r = e / (MB / 4), kc = r % KCP, tap = r / KCP, m = m0 + 4 * m4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kc < A.Cin && m < A.Mout) v = ld4(A.w + ((size_t)tap * A.Cin + kc) * A.w_ld + A.m_off + m);
+        st4(Ws + (tap * KCP + kc) * MB + 4 * m4, v);
+    }
+    float4 bias[MTW][QUADS];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q) {
+            const int m = m0 + (wm * MTW + mt) * MT + S::quad_base(q, h);
+            bias[mt][q] = (EPI == EPI_FWD && m < A.Mout) ? ld4(A.bias + A.m_off + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+
+    auto origin = [&](int tl, int& b, int& y0, int& x0) {
+        b = tl / A.tiles; const int tile = tl % A.tiles;
+        x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;
+    };
+    auto in_origin = [&](int y0, int x0, int& iy0, int& ix0) {
+        iy0 = AMODE == A_NORMAL ? y0 - (KH - 1) / 2 : (AMODE == A_UPF ? y0 / 2 : 2 * y0 - 1);
+        ix0 = AMODE == A_NORMAL ? x0 - (KH - 1) / 2 : (AMODE == A_UPF ? x0 / 2 : 2 * x0 - 1);
+    };
+    float4 pf[NPF];
+    auto load_tile = [&](int tl) {
+        int b, y0, x0, iy0, ix0;
+        origin(tl, b, y0, x0); in_origin(y0, x0, iy0, ix0);
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int e = tid + k * kBlock;
+            const int q = e % (KCP / 4), p = e / (KCP / 4), lx = p % IW, ly = p / IW;
+            const int gy = iy0 + ly, gx = ix0 + lx, c = 4 * q;
+            pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < (KCP / 4) * IH * IW && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
+                const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
+                const float* src = ((A.flags & F_TWO) && c >= A.C0) ? A.x1 + pix * A.C1 + (c - A.C0) : A.x0 + pix * A.C0 + c;
+                pf[k] = ld4(src);
+            }
+        }
+    };
+    auto store_tile = [&](int tl, float* dst) {
+        int b, y0, x0, iy0, ix0;
+        origin(tl, b, y0, x0); in_origin(y0, x0, iy0, ix0);
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int e = tid + k * kBlock;
+            if (e < (KCP / 4) * IH * IW) {
+                const int q = e % (KCP / 4), p = e / (KCP / 4), lx = p % IW, ly = p / IW;
+                const int gy = iy0 + ly, gx = ix0 + lx, c = 4 * q;
+                float4 v = pf[k];
+                if (gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
+                    const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
+                    const float* ab = A.ab0; int C = A.C0, cc = c;
+                    if ((A.flags & F_TWO) && c >= A.C0) { ab = A.ab1; C = A.C1; cc = c - A.C0; }
+                    if (A.flags & F_AFF) {
+                        const float4 a = ld4(ab + cc), bb = ld4(ab + C + cc);
+                        v.x = fmaxf(fmaf(a.x, v.x, bb.x), 0.f); v.y = fmaxf(fmaf(a.y, v.y, bb.y), 0.f);
+                        v.z = fmaxf(fmaf(a.z, v.z, bb.z), 0.f); v.w = fmaxf(fmaf(a.w, v.w, bb.w), 0.f);
+                    }
+                    if (A.flags & F_DROP) {
+                        const uint32_t el = (uint32_t)(pix * C + cc);
+                        v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
+                        v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
+                    }
+                }
+                float* d = dst + (4 * q) * PLANE + ly * IW + lx;
+                d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
+            }
+        }
+    };
+
+    int boff[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
+        boff[nt] = AMODE == A_NORMAL ? r * IW + xs : (AMODE == A_UPF ? 0 : (2 * r) * IW + 2 * xs);
+    }
+    float s1[MTW][ACC], s2[MTW][ACC];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < ACC; ++r) { s1[mt][r] = 0.f; s2[mt][r] = 0.f; }
+
+    const int step = gridDim.x;
+    if ((int)blockIdx.x < A.total_tiles) load_tile(blockIdx.x);
+    int buf = 0;
+    for (int tl = blockIdx.x; tl < A.total_tiles; tl += step, buf ^= 1) {
+        const float* Ib = Is[buf];
+        store_tile(tl, Is[buf]);
+        __syncthreads();            // tile image (and, first time, the weights) visible; buffer buf^1 is free again
+        if (tl + step < A.total_tiles) load_tile(tl + step);
+        int b, y0, x0;
+        origin(tl, b, y0, x0);
+
+        // producer's z for the epilogue mask: issued now, consumed after the MFMA loop
+        float4 zq[NTW][MTW][QUADS];
+        if constexpr (EPI == EPI_MASK) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
+                const int y = y0 + r, x = x0 + xs;
+                const bool pvalid = y < A.Ho && x < A.Wo;
+                const size_t pix = pvalid ? ((size_t)b * A.Ho + y) * A.Wo + x : 0;
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int q = 0; q < QUADS; ++q) {
+                        const int m = m0 + (wm * MTW + mt) * MT + S::quad_base(q, h);
+                        zq[nt][mt][q] = (pvalid && m < A.Mout) ? ld4(A.zin + pix * A.Mout + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
+        }
+
+        typename S::acc_t acc[MTW][NTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < ACC; ++r) acc[mt][nt][r] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < KH; ++kx) {
+                const int tap = ky * KH + kx;
+                int tapoff[NTW];
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    if constexpr (AMODE == A_UPF) {
+                        const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
+                        tapoff[nt] = ((r + ky) >> 1) * IW + ((xs + kx) >> 1);
+                    } else {
+                        tapoff[nt] = boff[nt] + ky * IW + kx;
+                    }
+                }
+                for (int ks = 0; ks < nks; ++ks) {
+                    const int kc = ks * KS + kk;
+                    float a[MTW], bv[NTW];
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) a[mt] = Ws[(tap * KCP + kc) * MB + (wm * MTW + mt) * MT + j];
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) bv[nt] = Ib[kc * PLANE + tapoff[nt]];
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = S::mfma(a[mt], bv[nt], acc[mt][nt]);
+                }
+            }
+        }
+
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
+            const int y = y0 + r, x = x0 + xs;
+            const bool pvalid = y < A.Ho && x < A.Wo;
+            const size_t pix = pvalid ? ((size_t)b * A.Ho + y) * A.Wo + x : 0;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+                for (int q = 0; q < QUADS; ++q) {
+                    const int m = m0 + (wm * MTW + mt) * MT + S::quad_base(q, h);
+                    const bool valid = pvalid && m < A.Mout;
+                    float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                    if constexpr (EPI == EPI_FWD) {
+                        v[0] += bias[mt][q].x; v[1] += bias[mt][q].y; v[2] += bias[mt][q].z; v[3] += bias[mt][q].w;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float u = valid ? v[k] : 0.f;
+                            s1[mt][4 * q + k] += u; s2[mt][4 * q + k] += u * u;
+                        }
+                    } else if constexpr (EPI == EPI_MASK) {
+                        const float zz[4] = {zq[nt][mt][q].x, zq[nt][mt][q].y, zq[nt][mt][q].z, zq[nt][mt][q].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int c = valid ? m + k : 0;
+                            const float yv = fmaf(A.bnin[BN_A * A.Mout + c], zz[k], A.bnin[BN_B * A.Mout + c]);
+                            float gv = v[k];
+                            if (A.drop_out) gv *= drop_mul(A.drop, (uint32_t)(pix * A.Mout + c));
+                            gv = (valid && yv > 0.f) ? gv : 0.f;
+                            const float xh = (zz[k] - A.bnin[BN_MEAN * A.Mout + c]) * A.bnin[BN_RSTD * A.Mout + c];
+                            v[k] = gv; s1[mt][4 * q + k] += gv; s2[mt][4 * q + k] += gv * xh;
+                        }
+                    }
+                    if (valid) st4(A.out + pix * A.Mout + m, make_float4(v[0], v[1], v[2], v[3]));
+                }
+            }
+        }
+    }
+
+    if constexpr (EPI != EPI_RAW) {
+        if (A.part) {
+            constexpr int OFF0 = NT / 2;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                subgroup_reduce_rec<ACC, ACC, OFF0>(s1[mt], lane);
+                subgroup_reduce_rec<ACC, ACC, OFF0>(s2[mt], lane);
+                const int ci = sub_chan<ACC, OFF0>(lane);
+                const int mloc = S::quad_base(ci >> 2, h) + (ci & 3);
+                red[((wave * 2 + 0) * MTW + mt) * MT + mloc] = s1[mt][0];
+                red[((wave * 2 + 1) * MTW + mt) * MT + mloc] = s2[mt][0];
+            }
+            __syncthreads();
+            if (tid < 2 * MB) {
+                const int stat = tid / MB, ml = tid % MB;
+                const int mtile = ml / MT, wmm = mtile / MTW, mt = mtile % MTW, mloc = ml % MT;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) s += red[(((wmm * WN + w) * 2 + stat) * MTW + mt) * MT + mloc];
+                if (m0 + ml < A.Mout)
+                    A.part[(size_t)blockIdx.x * (2 * A.Mout) + (size_t)stat * A.Mout + m0 + ml] = s;
             }
         }
     }

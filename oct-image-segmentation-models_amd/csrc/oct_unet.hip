@@ -20,6 +20,7 @@ using namespace oct;
 namespace {
 
 thread_local std::string g_err;
+int g_persist_min_tiles = 2048;   // pixel tiles from which thin single-chunk convs use the persistent pipelined kernel
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 #define HIP_OK(expr)                                                                               \
@@ -268,29 +269,51 @@ SrcDesc src_of(const oct_unet* h, int li, const void* x_in, int x_is_u8) {
 
 // ---- MFMA implicit-GEMM launcher: picks the MFMA shape from the channel count and the pixel tile from the grid size ----
 template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN>
-int launch_igemm_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes) {
+int launch_igemm_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
     a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH);
     dim3 grid(a.tiles, cdiv(a.Mout, MB), B), block(kBlock);
     char nm[48]; snprintf(nm, sizeof nm, "conv_igemm_k<%d,%d,%d,%d,%d,%d>", SHAPE, KH, AMODE, EPI, TH, MB);
     ProfScope ps(s, nm, layer, flops, bytes);
     conv_igemm_k<SHAPE, KH, AMODE, EPI, TH, MB, WN><<<grid, block, 0, s>>>(a);
     HIP_OK(hipGetLastError());
-    return a.tiles;   // > 0: number of pixel tiles per image (rows of statistic partials = B * tiles)
+    *rows = B * a.tiles;   // one statistic partial row per (image, pixel tile)
+    return 0;
+}
+
+// persistent pipelined variant (single K chunk): returns the number of statistic partial rows (= blocks along x)
+template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN, int KCP>
+int launch_igemm_p(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+    a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH); a.total_tiles = B * a.tiles;
+    const int nblk = std::min(a.total_tiles, 1280);    // ~5 resident blocks per CU
+    dim3 grid(nblk, cdiv(a.Mout, MB), 1), block(kBlock);
+    char nm[48]; snprintf(nm, sizeof nm, "conv_igemm_p_k<%d,%d,%d,%d,%d,%d,%d>", SHAPE, KH, AMODE, EPI, TH, MB, KCP);
+    ProfScope ps(s, nm, layer, flops, bytes);
+    conv_igemm_p_k<SHAPE, KH, AMODE, EPI, TH, MB, WN, KCP><<<grid, block, 0, s>>>(a);
+    HIP_OK(hipGetLastError());
+    *rows = nblk;       // one statistic partial row per block
+    return 0;
 }
 
 template <int KH, int AMODE, int EPI>
-int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes) {
+int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
     auto blocks = [&](int th, int mb) { return (long)B * cdiv(a.Ho, th) * cdiv(a.Wo, 32) * cdiv(a.Mout, mb); };
+    if constexpr (AMODE != A_DOWN2) {
+        // thin single-chunk layers with plenty of pixel tiles: persistent software-pipelined kernel
+        if (a.Cin <= 16 && a.Mout <= 16 && blocks(8, 16) >= g_persist_min_tiles) {
+            if (a.Cin <= 8) return launch_igemm_p<16, KH, AMODE, EPI, 8, 16, 4, 8>(a, B, s, layer, flops, bytes, rows);
+            return launch_igemm_p<16, KH, AMODE, EPI, 8, 16, 4, 16>(a, B, s, layer, flops, bytes, rows);
+        }
+    }
     if (a.Mout <= 16) {
-        if (blocks(8, 16) >= 512) return launch_igemm_geo<16, KH, AMODE, EPI, 8, 16, 4>(a, B, s, layer, flops, bytes);
-        return launch_igemm_geo<16, KH, AMODE, EPI, 4, 16, 4>(a, B, s, layer, flops, bytes);
+        if (blocks(8, 16) >= 512) return launch_igemm_geo<16, KH, AMODE, EPI, 8, 16, 4>(a, B, s, layer, flops, bytes, rows);
+        return launch_igemm_geo<16, KH, AMODE, EPI, 4, 16, 4>(a, B, s, layer, flops, bytes, rows);
     }
     if (a.Mout <= 32) {
-        if (blocks(8, 32) >= 512) return launch_igemm_geo<32, KH, AMODE, EPI, 8, 32, 4>(a, B, s, layer, flops, bytes);
-        return launch_igemm_geo<32, KH, AMODE, EPI, 4, 32, 4>(a, B, s, layer, flops, bytes);
+        if (blocks(8, 32) >= 512) return launch_igemm_geo<32, KH, AMODE, EPI, 8, 32, 4>(a, B, s, layer, flops, bytes, rows);
+        return launch_igemm_geo<32, KH, AMODE, EPI, 4, 32, 4>(a, B, s, layer, flops, bytes, rows);
     }
-    if (blocks(4, 64) >= 512) return launch_igemm_geo<32, KH, AMODE, EPI, 4, 64, 4>(a, B, s, layer, flops, bytes);
-    return launch_igemm_geo<32, KH, AMODE, EPI, 2, 64, 2>(a, B, s, layer, flops, bytes);
+    if (blocks(4, 64) >= 512) return launch_igemm_geo<32, KH, AMODE, EPI, 4, 64, 4>(a, B, s, layer, flops, bytes, rows);
+    return launch_igemm_geo<32, KH, AMODE, EPI, 2, 64, 2>(a, B, s, layer, flops, bytes, rows);
 }
 
 // algorithmic bytes of a conv's logical input, read once: low-res tensor for an up-conv, both
@@ -324,10 +347,8 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
         g.Cin = l.cin; g.w = a.w; g.w_ld = l.cout; g.m_off = 0; g.bias = a.bias; g.out = l.z; g.Mout = l.cout;
         g.Ho = l.H; g.Wo = l.W; g.Hi = l.src == SRC_UP ? l.H / 2 : l.H; g.Wi = l.src == SRC_UP ? l.W / 2 : l.W;
         g.part = a.part; g.drop = a.drop;
-        const int t = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, B, s, l.name, fl, by)
-                                      : launch_igemm<3, A_NORMAL, EPI_FWD>(g, B, s, l.name, fl, by);
-        if (t < 0) return t;
-        stat_rows = B * t; rc = 0;
+        rc = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows)
+                             : launch_igemm<3, A_NORMAL, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows);
     } else
     switch (l.src) {
         case SRC_INPUT: rc = x_is_u8 ? launch_conv_fwd_co<3, F_U8>(a, B, s, l.name, fl, by) : launch_conv_fwd_co<3, 0>(a, B, s, l.name, fl, by); break;
@@ -540,6 +561,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         if (rc) return rc;
         if (l.src == SRC_INPUT) break;
         // backward-data through the MFMA implicit-GEMM kernel: dz (plain) x transposed / effective weights
+        int rows = 0;
         auto dx = [&](float* gout, int Cg, int ci_off, const Layer* prod, bool up) -> int {
             IgemmArgs g{};
             g.x0 = l.g; g.C0 = l.cout; g.flags = 0; g.Cin = l.cout;
@@ -550,22 +572,22 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             const double px = (double)B * l.H * l.W, pxg = (double)B * g.Ho * g.Wo;
             const double fl = 2.0 * l.kh * l.kw * Cg * l.cout * px;          // algorithmic flops of the original conv's dX
             const double by = px * l.cout * 4 + pxg * Cg * 4 * (prod ? 2 : 1);
-            if (up) return launch_igemm<3, A_DOWN2, EPI_MASK>(g, B, s, l.name, fl, by);
-            return prod ? launch_igemm<3, A_NORMAL, EPI_MASK>(g, B, s, l.name, fl, by)
-                        : launch_igemm<3, A_NORMAL, EPI_RAW>(g, B, s, l.name, fl, by);
+            if (up) return launch_igemm<3, A_DOWN2, EPI_MASK>(g, B, s, l.name, fl, by, &rows);
+            return prod ? launch_igemm<3, A_NORMAL, EPI_MASK>(g, B, s, l.name, fl, by, &rows)
+                        : launch_igemm<3, A_NORMAL, EPI_RAW>(g, B, s, l.name, fl, by, &rows);
         };
         switch (l.src) {
             case SRC_PREV: {
                 Layer& p = pl.L[li - 1];
-                const int t = dx(p.g, p.cout, 0, &p, false);
-                if (t < 0) return t;
-                pending_nblk = B * t;
+                rc = dx(p.g, p.cout, 0, &p, false);
+                if (rc) return rc;
+                pending_nblk = rows;
                 break;
             }
             case SRC_POOL: {  // gradient wrt the pooled tensor (raw), then route through the pool into block li-1
                 Layer& p = pl.L[li - 1];
-                const int t = dx(h->gpooled[l.level - 1], l.cin, 0, nullptr, false);
-                if (t < 0) return t;
+                rc = dx(h->gpooled[l.level - 1], l.cin, 0, nullptr, false);
+                if (rc) return rc;
                 PoolBwdArgs pb{};
                 pb.gp = h->gpooled[l.level - 1]; pb.z = p.z; pb.bn = p.bn; pb.g = p.g; pb.part = h->stat_part;
                 pb.H = p.H; pb.W = p.W; pb.C = p.cout; pb.tiles_x = cdiv(p.W / 2, kTileX); pb.tiles = tiles_of(p.H / 2, p.W / 2);
@@ -579,20 +601,20 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             }
             case SRC_UP: {
                 Layer& p = pl.L[li - 1];
-                const int t = dx(p.g, p.cout, 0, &p, true);
-                if (t < 0) return t;
-                pending_nblk = B * t;
+                rc = dx(p.g, p.cout, 0, &p, true);
+                if (rc) return rc;
+                pending_nblk = rows;
                 break;
             }
             case SRC_CONCAT: {
                 Layer& p = pl.L[li - 1]; Layer& k = pl.L[l.skip_from];
                 // skip half first (raw, merged later by pool_bwd of that encoder level) ...
-                int t = dx(k.g, k.cout, p.cout, nullptr, false);
-                if (t < 0) return t;
+                rc = dx(k.g, k.cout, p.cout, nullptr, false);
+                if (rc) return rc;
                 // ... then the up-path half, whose statistics must be the ones pending for block li-1
-                t = dx(p.g, p.cout, 0, &p, false);
-                if (t < 0) return t;
-                pending_nblk = B * t;
+                rc = dx(p.g, p.cout, 0, &p, false);
+                if (rc) return rc;
+                pending_nblk = rows;
                 break;
             }
             default: return fail(-3, "backward: bad src");
@@ -809,6 +831,12 @@ int oct_unet_profile_end(oct_unet* h, oct_profile_entry* out, int max_entries, i
     *n_out = (int)agg.size();
     for (int i = 0; i < (int)agg.size() && i < max_entries && out; ++i) out[i] = agg[i];
     return 0;
+}
+
+int oct_set_option(const char* name, int value) {
+    if (!name) return fail(-1, "null option name");
+    if (!strcmp(name, "igemm_persistent_min_tiles")) { g_persist_min_tiles = value < 1 ? 1 : value; return 0; }
+    return fail(-1, std::string("unknown option: ") + name);
 }
 
 const float* oct_unet_debug_activation(oct_unet* h, int layer, int which) {

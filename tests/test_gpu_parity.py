@@ -53,8 +53,18 @@ MARGIN_SEED = {CASES[0]: 97, CASES[1]: 13, CASES[2]: 28, CASES[3]: 75}
 DROP_STEP = 3
 
 
+@pytest.fixture(params=["tile_per_block", "persistent"])
+def variant(request):
+    """Run the same verified inputs through both conv kernel variants for thin layers (the persistent
+    software-pipelined one is otherwise only chosen on large grids)."""
+    from oct_image_segmentation_models_amd import _hip
+    _hip.set_option("igemm_persistent_min_tiles", 1 if request.param == "persistent" else 1 << 30)
+    yield request.param
+    _hip.set_option("igemm_persistent_min_tiles", 2048)
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_inference_forward_matches_oracle(case):
+def test_inference_forward_matches_oracle(case, variant):
     B, H, W, C, sn, P, L, ic = case
     cfg, eng, p64, s64 = make(B, H, W, C, sn, P, L, ic, training=False)
     images, labels = data(B, H, W, C, ic)
@@ -81,7 +91,7 @@ def test_inference_forward_matches_oracle(case):
 
 @pytest.mark.parametrize("macro", [True, False])
 @pytest.mark.parametrize("case", CASES)
-def test_training_step_matches_oracle(case, macro):
+def test_training_step_matches_oracle(case, macro, variant):
     B, H, W, C, sn, P, L, ic = case
     cfg, eng, p64, s64 = make(B, H, W, C, sn, P, L, ic, training=True)
     images, labels = data(B, H, W, C, ic, seed=MARGIN_SEED[case])
