@@ -231,62 +231,83 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_k(float* __restrict__ g, 
     }
 }
 
-// ---- head backward: Dice gradient -> softmax Jacobian -> 1x1 conv backward-data -> mask + stats ----------------
+// ---- head backward: Dice gradient -> softmax Jacobian -> 1x1 conv backward (data AND weights) -> mask + stats ------
+// Everything the head needs is in registers here (y, p, dlogits), so its dW/db are accumulated in the same pass:
+// no dlogits tensor, no second read of z.  grid (nblk, B); a block walks chunks of one image and emits one row of
+// BN-backward statistics and one row of head-weight partials.
 struct HeadBwdArgs {
     const float* z; const float* bn;     // last conv block
     const float* w; const float* bias;   // head (CIN,C),(C)
     const unsigned char* labels;
     const double* bc;                    // Dice constants from dice_finalize_k
-    float* dlogits;                      // (B,H,W,C)
     float* g;                            // (B,H,W,CIN) masked gradient of the last conv block
-    float* part;                         // [B*nblk][2*CIN]
+    float* part;                         // [B*nblk][2*CIN]       BN-backward statistics
+    float* wpart;                        // [B*nblk][CIN*C + C]   head kernel / bias gradient partials
     int HW, nblk, B, macro; float loss_scale;
 };
 
 template <int C, int CIN>
 __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
+    constexpr int NV = CIN * C + C, NG = (NV + 31) / 32;
     __shared__ float red[256];
     const int b = blockIdx.y;
-    const int px = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = px < A.HW;
-    const size_t pix = (size_t)b * A.HW + (valid ? px : 0);
-    float y[CIN], zr[CIN], p[C];
-    head_logits<C, CIN>(A.z + pix * CIN, A.bn, A.w, A.bias, y, zr, p);
-    const int lab = A.labels[pix];
-    float dp[C], dot = 0.f;
+    float s1[CIN], s2[CIN], wv[NG * 32];
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NG * 32; ++i) wv[i] = 0.f;
+    float num[C], den[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const double* k = A.macro ? A.bc + 2 * (b * C + c) : A.bc + 2 * A.B * C;
-        const float num = (float)k[0], den = (float)k[1];
-        const float yv = lab == c ? 1.f : 0.f;
-        const float scale = A.macro ? A.loss_scale / (float)(A.B * C) : A.loss_scale;
-        dp[c] = -scale * (2.f * yv * den - num) / (den * den);
-        dot = fmaf(p[c], dp[c], dot);
+        num[c] = (float)k[0]; den[c] = (float)k[1];
     }
-    float dl[C];
+    const float scale = A.macro ? A.loss_scale / (float)(A.B * C) : A.loss_scale;
+
+    for (int chunk = blockIdx.x; chunk * kBlock < A.HW; chunk += gridDim.x) {
+        const int px = chunk * kBlock + threadIdx.x;
+        const bool valid = px < A.HW;
+        const size_t pix = (size_t)b * A.HW + (valid ? px : 0);
+        float y[CIN], zr[CIN], p[C];
+        head_logits<C, CIN>(A.z + pix * CIN, A.bn, A.w, A.bias, y, zr, p);
+        const int lab = A.labels[pix];
+        float dp[C], dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) dl[c] = valid ? p[c] * (dp[c] - dot) : 0.f;
-    if (valid) {
+        for (int c = 0; c < C; ++c) {
+            const float yv = lab == c ? 1.f : 0.f;
+            dp[c] = -scale * (2.f * yv * den[c] - num[c]) / (den[c] * den[c]);
+            dot = fmaf(p[c], dp[c], dot);
+        }
+        float dl[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) A.dlogits[pix * C + c] = dl[c];
+        for (int c = 0; c < C; ++c) { dl[c] = valid ? p[c] * (dp[c] - dot) : 0.f; wv[CIN * C + c] += dl[c]; }
+        float g[CIN];
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { a = fmaf(A.w[i * C + c], dl[c], a); wv[i * C + c] = fmaf(y[i], dl[c], wv[i * C + c]); }
+            a = (valid && y[i] > 0.f) ? a : 0.f;
+            const float xh = (zr[i] - A.bn[BN_MEAN * CIN + i]) * A.bn[BN_RSTD * CIN + i];
+            g[i] = a; s1[i] += a; s2[i] += a * xh;
+        }
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < CIN; i += 4) st4(A.g + pix * CIN + i, make_float4(g[i], g[i + 1], g[i + 2], g[i + 3]));
+        }
     }
-    float g[CIN], s1[CIN], s2[CIN];
-#pragma unroll
-    for (int i = 0; i < CIN; ++i) {
-        float a = 0.f;
-#pragma unroll
-        for (int c = 0; c < C; ++c) a = fmaf(A.w[i * C + c], dl[c], a);
-        a = (valid && y[i] > 0.f) ? a : 0.f;
-        const float xh = (zr[i] - A.bn[BN_MEAN * CIN + i]) * A.bn[BN_RSTD * CIN + i];
-        g[i] = a; s1[i] = a; s2[i] = a * xh;
-    }
-    if (valid) {
-#pragma unroll
-        for (int i = 0; i < CIN; i += 4) st4(A.g + pix * CIN + i, make_float4(g[i], g[i + 1], g[i + 2], g[i + 3]));
-    }
-    float* out = A.part + ((size_t)b * A.nblk + blockIdx.x) * (2 * CIN);
+    const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+    float* out = A.part + row * (2 * CIN);
     block_reduce_store<CIN>(s1, red, out, CIN);
     block_reduce_store<CIN>(s2, red, out + CIN, CIN);
+    float* wout = A.wpart + row * NV;
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        float t[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t[k] = wv[gi * 32 + k];
+        block_reduce_store<32>(t, red, wout + gi * 32, NV - gi * 32 < 32 ? NV - gi * 32 : 32);
+    }
 }
 
 // ---- conv backward-weights (LDS-staged tiles, per-block partial dW, deterministic second-stage sum) ------------

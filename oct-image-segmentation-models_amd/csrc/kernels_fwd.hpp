@@ -236,43 +236,45 @@ __device__ inline void head_logits(const float* __restrict__ zp, const float* __
     for (int c = 0; c < C; ++c) p[c] *= inv;
 }
 
+// grid (nblk, B): each block walks the 256-pixel chunks  blockIdx.x, blockIdx.x + nblk, ...  of ONE image and emits
+// one row of Dice partial sums
 template <int C, int CIN>
 __global__ __launch_bounds__(kBlock) void head_fwd_k(const HeadFwdArgs A) {
     constexpr int N = DiceN<C>::value;
     __shared__ float red[256];
     const int b = blockIdx.y;
-    const int px = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = px < A.HW;
-    const size_t pix = (size_t)b * A.HW + (valid ? px : 0);
-    float y[CIN], zr[CIN], p[C];
-    head_logits<C, CIN>(A.z + pix * CIN, A.ab, A.w, A.bias, y, zr, p);
-    if (valid) {
-        if (A.probs) {
+    float v[N];
 #pragma unroll
-            for (int c = 0; c < C; ++c) A.probs[pix * C + c] = p[c];
-        }
-        if (A.argmax) {
-            int am = 0; float best = p[0];
-#pragma unroll
-            for (int c = 1; c < C; ++c) if (p[c] > best) { best = p[c]; am = c; }  // first maximum, as np.argmax
-            A.argmax[pix] = (unsigned char)am;
-        }
-    }
-    if (A.labels) {
-        float v[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = 0.f;
+    for (int i = 0; i < N; ++i) v[i] = 0.f;
+    for (int chunk = blockIdx.x; chunk * kBlock < A.HW; chunk += gridDim.x) {
+        const int px = chunk * kBlock + threadIdx.x;
+        const bool valid = px < A.HW;
+        const size_t pix = (size_t)b * A.HW + (valid ? px : 0);
+        float y[CIN], zr[CIN], p[C];
+        head_logits<C, CIN>(A.z + pix * CIN, A.ab, A.w, A.bias, y, zr, p);
         if (valid) {
-            const int lab = A.labels[pix];
+            if (A.probs) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float yv = lab == c ? 1.f : 0.f, ph = p[c] > 0.5f ? 1.f : 0.f;
-                v[c * kDiceVals + 0] = yv * p[c]; v[c * kDiceVals + 1] = yv; v[c * kDiceVals + 2] = p[c];
-                v[c * kDiceVals + 3] = yv * ph;   v[c * kDiceVals + 4] = ph;
+                for (int c = 0; c < C; ++c) A.probs[pix * C + c] = p[c];
+            }
+            if (A.argmax) {
+                int am = 0; float best = p[0];
+#pragma unroll
+                for (int c = 1; c < C; ++c) if (p[c] > best) { best = p[c]; am = c; }  // first maximum, as np.argmax
+                A.argmax[pix] = (unsigned char)am;
+            }
+            if (A.labels) {
+                const int lab = A.labels[pix];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float yv = lab == c ? 1.f : 0.f, ph = p[c] > 0.5f ? 1.f : 0.f;
+                    v[c * kDiceVals + 0] += yv * p[c]; v[c * kDiceVals + 1] += yv; v[c * kDiceVals + 2] += p[c];
+                    v[c * kDiceVals + 3] += yv * ph;   v[c * kDiceVals + 4] += ph;
+                }
             }
         }
-        block_reduce_store<N>(v, red, A.dice_part + ((size_t)b * A.nblk + blockIdx.x) * N, N);
     }
+    if (A.labels) block_reduce_store<N>(v, red, A.dice_part + ((size_t)b * gridDim.x + blockIdx.x) * N, N);
 }
 
 // Dice finalize: per-(b,c) sums in fp64 -> losses, metrics, and the per-(b,c) constants backward needs.

@@ -170,7 +170,6 @@ struct oct_unet {
     float* stat_part = nullptr;            // BN statistic partials (fwd and bwd share it: stream-ordered)
     float* dw_part = nullptr;
     float* dice_part = nullptr; double* dice_bc = nullptr; float* loss4 = nullptr;
-    float* dlogits = nullptr;
     WtDesc* wt_descs = nullptr; int n_wt = 0; unsigned wt_total = 0;
     unsigned long long drop_step = 0; int drop_advance = 0;
     int last_B = 0; int last_training = 0; int have_dice = 0; int dice_final = 0;
@@ -199,6 +198,7 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
         if (c.training) {
             const size_t wsz = (size_t)l.kh * l.kw * l.cin * l.cout + l.cout;
             dw_max = std::max(dw_max, (size_t)dw_plan(l, c.max_batch).npb * wsz);
+            if (l.src == SRC_HEAD) dw_max = std::max(dw_max, (size_t)(2048 + c.max_batch) * wsz);
         }
     }
     for (int i = 0; i < pl.P; ++i) {
@@ -214,10 +214,9 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
     float* dp = (float*)take(B * nblk_head * 64 * 4);
     double* bc = (double*)take((B * 8 * 2 + 2) * 8);
     float* l4 = (float*)take(4 * 4);
-    float* dl = c.training ? (float*)take(B * c.H * c.W * c.n_cls * 4) : nullptr;
     WtDesc* wd = c.training ? (WtDesc*)take(pl.L.size() * sizeof(WtDesc)) : nullptr;
     if (h) h->wt_descs = wd;
-    if (h) { h->stat_part = sp; h->dw_part = dwp; h->dice_part = dp; h->dice_bc = bc; h->loss4 = l4; h->dlogits = dl; }
+    if (h) { h->stat_part = sp; h->dw_part = dwp; h->dice_part = dp; h->dice_bc = bc; h->loss4 = l4; }
     return off;
 }
 
@@ -393,7 +392,7 @@ int launch_head_bwd(const HeadBwdArgs& a, int cin, int B, hipStream_t s) {
     dim3 grid(a.nblk, B), block(kBlock);
     const double px = (double)B * a.HW;
     char nm[48]; snprintf(nm, sizeof nm, "head_bwd_k<%d,%d>", C, cin);
-    ProfScope ps(s, nm, "head", 4.0 * cin * C * px, px * (cin * 4 * 2 + C * 4 + 1));
+    ProfScope ps(s, nm, "head", 6.0 * cin * C * px, px * (cin * 4 * 2 + 1));
     switch (cin) {
         case 4: head_bwd_k<C, 4><<<grid, block, 0, s>>>(a); break;
         case 8: head_bwd_k<C, 8><<<grid, block, 0, s>>>(a); break;
@@ -417,6 +416,9 @@ int launch_head_bwd(const HeadBwdArgs& a, int cin, int B, hipStream_t s) {
             default: return fail(-3, "bad n_cls");      \
         }                                               \
     })()
+
+// blocks per image of the head kernels: ~2048 blocks in total, each walking several 256-pixel chunks
+int head_nblk(int HW, int B) { return std::max(1, std::min(cdiv(HW, kBlock), cdiv(2048, B))); }
 
 int dice_n(int C) { return 5 * C <= 16 ? 16 : (5 * C <= 32 ? 32 : 64); }
 
@@ -450,7 +452,7 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
     HeadFwdArgs a{};
     a.z = last.z; a.ab = last.bn; a.w = h->params + hd.w_off; a.bias = h->params + hd.b_off;
     a.probs = io ? io->probs : nullptr; a.argmax = io ? io->argmax : nullptr; a.labels = io ? io->labels : nullptr;
-    a.dice_part = h->dice_part; a.HW = hd.H * hd.W; a.nblk = cdiv(a.HW, kBlock);
+    a.dice_part = h->dice_part; a.HW = hd.H * hd.W; a.nblk = head_nblk(a.HW, B);
     const int rc = DISPATCH_C(launch_head_fwd, h->cfg.n_cls, a, hd.cin, B, s);
     if (rc) return rc;
     h->last_B = B; h->last_training = training; h->have_dice = a.labels != nullptr;
@@ -467,7 +469,6 @@ int launch_dw(const ConvBwdWArgs& a, int ci_t, int co_t, hipStream_t s, const ch
     ProfScope ps(s, nm, layer, flops, bytes);
 #define DW_CASE(CI, CO) if (ci_t == CI && co_t == CO) { conv_bwd_w_k<KH, CI, CO><<<grid, block, 0, s>>>(a); HIP_OK(hipGetLastError()); return 0; }
     DW_CASE(1, 4) DW_CASE(1, 8) DW_CASE(1, 16)
-    DW_CASE(4, 4) DW_CASE(4, 8) DW_CASE(8, 4) DW_CASE(8, 8) DW_CASE(16, 4) DW_CASE(16, 8)
 #undef DW_CASE
     return fail(-3, "dW: unsupported channel chunking");
 }
@@ -488,10 +489,7 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const fl
     const bool up = l.src == SRC_UP;
     int rc = 0;
     if (p.kind == 0) {
-        switch (l.kh) {
-            case 1: rc = launch_dw<1>(a, p.cic, p.coc, s, l.name, fl, by); break;
-            default: rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by); break;
-        }
+        rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by);   // 1-channel (or odd-channel) first layer
     } else {
         dim3 grid(p.npb, cdiv(l.cin, p.cic), cdiv(l.cout, p.coc)), block(kBlock);
         char nm[48]; snprintf(nm, sizeof nm, "conv_dw%d_k<%d,%d,%d>", p.kind, l.kh, p.cic, (int)up);
@@ -539,8 +537,8 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     // head: dlogits, masked gradient of the last block + its statistics
     HeadBwdArgs hb{};
     hb.z = last.z; hb.bn = last.bn; hb.w = h->params + hd.w_off; hb.bias = h->params + hd.b_off;
-    hb.labels = labels; hb.bc = h->dice_bc; hb.dlogits = h->dlogits; hb.g = last.g; hb.part = h->stat_part;
-    hb.HW = hd.H * hd.W; hb.nblk = cdiv(hb.HW, kBlock); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale;
+    hb.labels = labels; hb.bc = h->dice_bc; hb.g = last.g; hb.part = h->stat_part; hb.wpart = h->dw_part;
+    hb.HW = hd.H * hd.W; hb.nblk = head_nblk(hb.HW, B); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale;
     {   // backward-data weights of every block for this step's parameters (one launch)
         ProfScope ps(s, "prep_wt_k", "all", 0, (double)h->wt_total * 8);
         prep_wt_k<<<std::min<unsigned>((h->wt_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wt_descs, h->n_wt, h->wt_total);
@@ -549,8 +547,13 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     int rc = DISPATCH_C(launch_head_bwd, h->cfg.n_cls, hb, hd.cin, B, s);
     if (rc) return rc;
     int pending_nblk = B * hb.nblk;           // number of stat partial rows waiting for block (li-1)
-    rc = conv_backward_w(h, nl - 1, x_in, x_is_u8, h->dlogits, B, s);
-    if (rc) return rc;
+    {   // head kernel/bias gradient: sum the per-block rows written by head_bwd_k
+        const size_t wsize = (size_t)hd.cin * hd.cout, stride = wsize + hd.cout;
+        ProfScope ps(s, "reduce_partials_k", "head", 0, (double)pending_nblk * stride * 4);
+        reduce_partials_k<16><<<(int)((stride + 15) / 16), kBlock, 0, s>>>(h->dw_part, pending_nblk, stride, wsize,
+                                                                          h->grads + hd.w_off, h->grads + hd.b_off);
+        HIP_OK(hipGetLastError());
+    }
 
     for (int li = nl - 2; li >= 0; --li) {
         Layer& l = pl.L[li];
@@ -731,7 +734,7 @@ int oct_unet_loss_dice(oct_unet* h, float smooth, float* out4, oct_stream_t stre
     if (!h) return fail(-1, "null handle");
     if (!h->have_dice) return fail(-1, "loss_dice needs a preceding forward with io.labels");
     DiceFinArgs a{};
-    a.part = h->dice_part; a.B = h->last_B; a.C = h->cfg.n_cls; a.nblk = cdiv(h->cfg.H * h->cfg.W, kBlock);
+    a.part = h->dice_part; a.B = h->last_B; a.C = h->cfg.n_cls; a.nblk = head_nblk(h->cfg.H * h->cfg.W, h->last_B);
     a.N = dice_n(a.C); a.smooth = smooth; a.out4 = h->loss4; a.out4_user = out4; a.bc = h->dice_bc;
     dice_finalize_k<<<1, kBlock, 0, (hipStream_t)stream>>>(a);
     HIP_OK(hipGetLastError());
