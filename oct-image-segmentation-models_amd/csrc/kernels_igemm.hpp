@@ -85,6 +85,56 @@ __device__ inline int sub_chan(int lane) {
     return c;
 }
 
+// ---- MFMA sweep over one staged K chunk: flat (tap x k-step) sequence, fully unrolled, operands double-buffered
+// in registers so the LDS reads of step i+1 are in flight while the MFMAs of step i issue ----
+template <int SHAPE, int KH, int AMODE, int KCX, int MB, int IW, int PLANE, int NPR, int MTW, int NTW, bool FULL>
+__device__ __forceinline__ void mfma_sweep(const float* __restrict__ Ws, const float* __restrict__ Ib,
+                                           typename MfmaShape<SHAPE>::acc_t (&acc)[MTW][NTW], const int (&boff)[NTW],
+                                           int wn, int wm, int j, int kk, int nks) {
+    using S = MfmaShape<SHAPE>;
+    constexpr int MT = SHAPE, NT = SHAPE, KS = S::KS, NKS = KCX / KS, TAPS = KH * KH, STEPS = TAPS * NKS;
+    auto load = [&](int i, float (&a)[MTW], float (&bv)[NTW]) {
+        const int tap = i / NKS, ks = i % NKS, ky = tap / KH, kx = tap % KH, kc = ks * KS + kk;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) a[mt] = Ws[(tap * KCX + kc) * MB + (wm * MTW + mt) * MT + j];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            int off;
+            if constexpr (AMODE == A_UPF) {
+                const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
+                off = ((r + ky) >> 1) * IW + ((xs + kx) >> 1);
+            } else {
+                off = boff[nt] + ky * IW + kx;
+            }
+            bv[nt] = Ib[kc * PLANE + off];
+        }
+    };
+    auto fma = [&](const float (&a)[MTW], const float (&bv)[NTW]) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = S::mfma(a[mt], bv[nt], acc[mt][nt]);
+    };
+    if constexpr (FULL) {
+        float a0[MTW], b0[NTW], a1[MTW], b1[NTW];
+        load(0, a0, b0);
+#pragma unroll
+        for (int i = 0; i < STEPS; i += 2) {
+            if (i + 1 < STEPS) load(i + 1, a1, b1);
+            fma(a0, b0);
+            if (i + 2 < STEPS) load(i + 2, a0, b0);
+            if (i + 1 < STEPS) fma(a1, b1);
+        }
+    } else {   // fewer channels than the chunk holds (tiny test configurations): plain runtime loop
+        for (int tap = 0; tap < TAPS; ++tap)
+            for (int ks = 0; ks < nks; ++ks) {
+                float a[MTW], bv[NTW];
+                load(tap * NKS + ks, a, bv);
+                fma(a, bv);
+            }
+    }
+}
+
 // grid (tiles, ceil(Mout/MB), B), block 256 = 4 waves arranged WN (pixel tiles) x WM (channel tiles)
 template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN>
 __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
@@ -164,36 +214,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
         __syncthreads();
         // ---- MFMA over taps x k-steps (only the channels that exist: thin layers have Cin < KC) ----
         const int nks = (A.Cin - c0 < KC ? A.Cin - c0 : KC) / KS;
-#pragma unroll
-        for (int ky = 0; ky < KH; ++ky) {
-#pragma unroll
-            for (int kx = 0; kx < KH; ++kx) {
-                const int tap = ky * KH + kx;
-                int tapoff[NTW];
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    if constexpr (AMODE == A_UPF) {
-                        const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
-                        tapoff[nt] = ((r + ky) >> 1) * IW + ((xs + kx) >> 1);
-                    } else {
-                        tapoff[nt] = boff[nt] + ky * IW + kx;
-                    }
-                }
-#pragma unroll 2
-                for (int ks = 0; ks < nks; ++ks) {
-                    const int kc = ks * KS + kk;
-                    float a[MTW], bv[NTW];
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) a[mt] = Ws[(tap * KC + kc) * MB + (wm * MTW + mt) * MT + j];
-#pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) bv[nt] = Is[kc * PLANE + tapoff[nt]];
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = S::mfma(a[mt], bv[nt], acc[mt][nt]);
-                }
-            }
-        }
+        if (nks == KC / KS) mfma_sweep<SHAPE, KH, AMODE, KC, MB, IW, PLANE, NPR, MTW, NTW, true>(Ws, Is, acc, boff, wn, wm, j, kk, nks);
+        else mfma_sweep<SHAPE, KH, AMODE, KC, MB, IW, PLANE, NPR, MTW, NTW, false>(Ws, Is, acc, boff, wn, wm, j, kk, nks);
     }
 
     // ---- epilogue ----
@@ -424,35 +446,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
             for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int r = 0; r < ACC; ++r) acc[mt][nt][r] = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < KH; ++ky) {
-#pragma unroll
-            for (int kx = 0; kx < KH; ++kx) {
-                const int tap = ky * KH + kx;
-                int tapoff[NTW];
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    if constexpr (AMODE == A_UPF) {
-                        const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
-                        tapoff[nt] = ((r + ky) >> 1) * IW + ((xs + kx) >> 1);
-                    } else {
-                        tapoff[nt] = boff[nt] + ky * IW + kx;
-                    }
-                }
-                for (int ks = 0; ks < nks; ++ks) {
-                    const int kc = ks * KS + kk;
-                    float a[MTW], bv[NTW];
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) a[mt] = Ws[(tap * KCP + kc) * MB + (wm * MTW + mt) * MT + j];
-#pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) bv[nt] = Ib[kc * PLANE + tapoff[nt]];
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = S::mfma(a[mt], bv[nt], acc[mt][nt]);
-                }
-            }
-        }
+        if (nks == KCP / KS) mfma_sweep<SHAPE, KH, AMODE, KCP, MB, IW, PLANE, NPR, MTW, NTW, true>(Ws, Ib, acc, boff, wn, wm, j, kk, nks);
+        else mfma_sweep<SHAPE, KH, AMODE, KCP, MB, IW, PLANE, NPR, MTW, NTW, false>(Ws, Ib, acc, boff, wn, wm, j, kk, nks);
 
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
