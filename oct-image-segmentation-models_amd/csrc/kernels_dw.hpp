@@ -121,7 +121,8 @@ __global__ __launch_bounds__(kBlock) void conv_dw16_k(const ConvBwdWArgs A) {
     constexpr int LDSN = (XS + DS > RED ? XS + DS : RED) > 1024 ? (XS + DS > RED ? XS + DS : RED) : 1024;
     __shared__ float lds[LDSN];
     float* Xs = lds; float* Ds = lds + XS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci0 = blockIdx.y * CIC, co0 = blockIdx.z * 16;
 
     int aoff[MTILES], aky[MTILES], akx[MTILES], aci[MTILES]; bool aval[MTILES];
@@ -207,13 +208,14 @@ __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
     constexpr int XS = IH * IW * CIC, DS = TH * TW * COC;
     __shared__ float lds[(XS + DS) > 1024 ? (XS + DS) : 1024];
     float* Xs = lds; float* Ds = lds + XS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, kk = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, kk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: unit guards become scalar branches
     const int ci0 = blockIdx.y * CIC, co0 = blockIdx.z * COC;
 
     int uky[UPW], ukx[UPW], umt[UPW];
 #pragma unroll
     for (int k = 0; k < UPW; ++k) {
-        const int u = wave + 4 * k, tap = u / MTB;
+        const int u = (wave + 4 * k < UNITS) ? wave + 4 * k : UNITS - 1, tap = u / MTB;
         umt[k] = u % MTB; uky[k] = tap / KH; ukx[k] = tap % KH;
     }
     f32x16 acc[UPW];
@@ -243,20 +245,31 @@ __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
             tile_of(tl + A.npb, nb, ny0, nx0);
             st.load(A, nb, ny0, nx0, ci0, co0);
         }
-#pragma unroll
-        for (int rr = 0; rr < TH; ++rr) {
-#pragma unroll 2
-            for (int ks = 0; ks < TW / 2; ++ks) {
-                const int p = 2 * ks + kk;
-                const float bv = Ds[(rr * TW + p) * COC + i];
+        {   // TH rows x 16 k-steps; the operands of step s+1 are read from LDS while the MFMAs of step s issue
+            constexpr int STEPS = TH * (TW / 2);
+            auto load = [&](int s, float (&a)[UPW], float& bv) {
+                const int rr = s / (TW / 2), p = 2 * (s % (TW / 2)) + kk;
+                bv = Ds[(rr * TW + p) * COC + i];
 #pragma unroll
                 for (int k = 0; k < UPW; ++k) {
-                    if (wave + 4 * k < UNITS) {   // wave-uniform
-                        int off;
-                        if constexpr (UP) off = (((rr + uky[k]) >> 1) * IW + ((p + ukx[k]) >> 1)) * CIC + umt[k] * 32 + i;
-                        else off = ((rr + uky[k]) * IW + p + ukx[k]) * CIC + umt[k] * 32 + i;
-                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[off], bv, acc[k], 0, 0, 0);
-                    }
+                    int off;
+                    if constexpr (UP) off = (((rr + uky[k]) >> 1) * IW + ((p + ukx[k]) >> 1)) * CIC + umt[k] * 32 + i;
+                    else off = ((rr + uky[k]) * IW + p + ukx[k]) * CIC + umt[k] * 32 + i;
+                    a[k] = Xs[off];   // the (possibly absent) last unit of a wave reads a clamped, valid address
+                }
+            };
+            float an[UPW], bn;
+            load(0, an, bn);
+#pragma unroll 2
+            for (int s = 0; s < STEPS; ++s) {
+                float a[UPW]; const float bv = bn;
+#pragma unroll
+                for (int k = 0; k < UPW; ++k) a[k] = an[k];
+                if (s + 1 < STEPS) load(s + 1, an, bn);
+#pragma unroll
+                for (int k = 0; k < UPW; ++k) {
+                    if (4 * k + 3 < UNITS || wave + 4 * k < UNITS)   // compile-time true except for the last unit
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], bv, acc[k], 0, 0, 0);
                 }
             }
         }

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
     __shared__ float Ws[TAPS * KC * MB];
     __shared__ float red[RED];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wm = wave / WN;
     const int j = lane & (NT - 1), kk = lane / NT, h = kk;   // B/A operand: column j (or row i), k index kk; D: lane half/quarter h
     const int tile = blockIdx.x, b = blockIdx.z, m0 = blockIdx.y * MB;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
     __shared__ float Ws[TAPS * KCP * MB];
     __shared__ float red[RED];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wm = wave / WN;
     const int j = lane & (NT - 1), kk = lane / NT, h = kk;
     const int m0 = blockIdx.y * MB;
