@@ -132,7 +132,9 @@ int oct_unet_profile_end(oct_unet* h, oct_profile_entry* out, int max_entries, i
 
 /* ---- tuning knobs (process-wide; results do not depend on them, only which kernel variant runs) ----
  *   "igemm_persistent_min_tiles" (default 2048): number of pixel tiles from which thin single-chunk convs use the
- *   persistent software-pipelined kernel instead of the one-tile-per-block kernel. */
+ *   persistent software-pipelined kernel instead of the one-tile-per-block kernel.
+ *   "thin8_min_tiles" (default 2048): number of pixel tiles from which 8-output-channel convs run on the VALU
+ *   thin-layer kernel instead of the (half-padded) 16x16 MFMA kernel. */
 int oct_set_option(const char* name, int value);
 
 /* ---- introspection for tests: device pointer of a layer's saved pre-BN output / gradient ---- */

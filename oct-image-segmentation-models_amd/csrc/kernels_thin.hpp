@@ -1,0 +1,199 @@
+// VALU convolution for the THIN full-resolution layers (8 output channels).
+//
+// With M = 8 every 16x16 MFMA is half padding, while the f32 VALU has the same peak rate as the f32 MFMA on
+// gfx950 (64 flop/clk/SIMD) and no tile padding -- so these HBM-bound layers run on the VALU:
+//   * block tile 8 rows x 64 cols, one thread = 2 adjacent pixels x 8 output channels (16 accumulators);
+//   * input tile (all <=16 input channels, halo included) in PLANAR LDS [c][row][col], transform applied on load;
+//     a thread reads its 3x4 window per channel with 8-byte ds_reads, conflict-free;
+//   * weights are wave-uniform -> scalar loads, used as SGPR operands of v_fma (no LDS, no VGPRs);
+//   * persistent over pixel tiles with the next tile's global loads in flight during the FMA loop;
+//   * same addressing modes / epilogues / argument block as the MFMA kernel (kernels_igemm.hpp).
+#pragma once
+#include "common.hpp"
+#include "kernels_igemm.hpp"
+
+namespace oct {
+
+// grid (nblk, 1, 1); requires Mout == 8, Cin <= 16 (Cin % 4 == 0), AMODE in {A_NORMAL (KH=3), A_UPF (KH=2)}
+template <int KH, int AMODE, int EPI, int CMAX>
+__global__ __launch_bounds__(kBlock) void conv_thin8_k(const IgemmArgs A, const float* __restrict__ wgt, float* __restrict__ outp) {
+    constexpr int TH = 8, TW = 64, M = 8, PX = 2;
+    constexpr int IH = AMODE == A_NORMAL ? TH + KH - 1 : TH / 2 + 1;
+    constexpr int IW = AMODE == A_NORMAL ? TW + KH - 1 : TW / 2 + 1;
+    constexpr int IWP = (IW + 1) & ~1;                     // even row stride: 8-byte aligned window reads
+    constexpr int PLANE = IH * IWP;
+    constexpr int NPF = ((CMAX / 4) * IH * IW + kBlock - 1) / kBlock;
+    __shared__ float Is[CMAX * PLANE];
+    __shared__ float red[256];
+
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;     // thread -> pixels (ty, 2*tx .. 2*tx+1)
+    const int tiles_x = A.tiles_x;
+
+    auto origin = [&](int tl, int& b, int& y0, int& x0) {
+        b = tl / A.tiles; const int tile = tl % A.tiles;
+        x0 = (tile % tiles_x) * TW; y0 = (tile / tiles_x) * TH;
+    };
+    float4 pf[NPF];
+    auto load_tile = [&](int tl) {
+        int b, y0, x0; origin(tl, b, y0, x0);
+        const int iy0 = AMODE == A_NORMAL ? y0 - 1 : y0 / 2, ix0 = AMODE == A_NORMAL ? x0 - 1 : x0 / 2;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int e = tid + k * kBlock;
+            const int q = e % (CMAX / 4), p = e / (CMAX / 4), lx = p % IW, ly = p / IW;
+            const int gy = iy0 + ly, gx = ix0 + lx, c = 4 * q;
+            pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < (CMAX / 4) * IH * IW && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
+                const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
+                pf[k] = ld4(((A.flags & F_TWO) && c >= A.C0) ? A.x1 + pix * A.C1 + (c - A.C0) : A.x0 + pix * A.C0 + c);
+            }
+        }
+    };
+    auto store_tile = [&](int tl) {
+        int b, y0, x0; origin(tl, b, y0, x0);
+        const int iy0 = AMODE == A_NORMAL ? y0 - 1 : y0 / 2, ix0 = AMODE == A_NORMAL ? x0 - 1 : x0 / 2;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int e = tid + k * kBlock;
+            if (e < (CMAX / 4) * IH * IW) {
+                const int q = e % (CMAX / 4), p = e / (CMAX / 4), lx = p % IW, ly = p / IW;
+                const int gy = iy0 + ly, gx = ix0 + lx, c = 4 * q;
+                float4 v = pf[k];
+                if (gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
+                    const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
+                    const float* ab = A.ab0; int C = A.C0, cc = c;
+                    if ((A.flags & F_TWO) && c >= A.C0) { ab = A.ab1; C = A.C1; cc = c - A.C0; }
+                    if (A.flags & F_AFF) {
+                        const float4 a = ld4(ab + cc), bb = ld4(ab + C + cc);
+                        v.x = fmaxf(fmaf(a.x, v.x, bb.x), 0.f); v.y = fmaxf(fmaf(a.y, v.y, bb.y), 0.f);
+                        v.z = fmaxf(fmaf(a.z, v.z, bb.z), 0.f); v.w = fmaxf(fmaf(a.w, v.w, bb.w), 0.f);
+                    }
+                    if (A.flags & F_DROP) {
+                        const uint32_t el = (uint32_t)(pix * C + cc);
+                        v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
+                        v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
+                    }
+                }
+                float* d = Is + (4 * q) * PLANE + ly * IWP + lx;
+                d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
+            }
+        }
+    };
+
+    float bias[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) bias[m] = EPI == EPI_FWD ? A.bias[A.m_off + m] : 0.f;
+    float s1[M], s2[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
+
+    const int step = gridDim.x;
+    if ((int)blockIdx.x < A.total_tiles) load_tile(blockIdx.x);
+    for (int tl = blockIdx.x; tl < A.total_tiles; tl += step) {
+        __syncthreads();                    // every wave has finished reading the previous tile image
+        store_tile(tl);
+        __syncthreads();
+        if (tl + step < A.total_tiles) load_tile(tl + step);
+        int b, y0, x0; origin(tl, b, y0, x0);
+        const int y = y0 + ty, x = x0 + 2 * tx;
+        const bool rowok = y < A.Ho;
+        float4 zq[PX][2];
+        if constexpr (EPI == EPI_MASK) {    // producer's z for the ReLU mask: in flight during the FMA loop
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                const bool ok = rowok && x + p < A.Wo;
+                const float* zp = A.zin + (((size_t)b * A.Ho + (ok ? y : 0)) * A.Wo + (ok ? x + p : 0)) * M;
+                zq[p][0] = ok ? ld4(zp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                zq[p][1] = ok ? ld4(zp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+
+        float acc[PX][M];
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[p][m] = bias[m];
+
+        for (int c = 0; c < A.Cin; ++c) {
+            const float* plane = Is + c * PLANE;
+            if constexpr (AMODE == A_NORMAL) {
+                float xw[KH][PX + KH - 1];   // 3 x 4 window of this thread's two pixels
+#pragma unroll
+                for (int r = 0; r < KH; ++r) {
+                    const float2 lo = *reinterpret_cast<const float2*>(plane + (ty + r) * IWP + 2 * tx);
+                    const float2 hi = *reinterpret_cast<const float2*>(plane + (ty + r) * IWP + 2 * tx + 2);
+                    xw[r][0] = lo.x; xw[r][1] = lo.y; xw[r][2] = hi.x; xw[r][3] = hi.y;
+                }
+#pragma unroll
+                for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < KH; ++kx) {
+                        const float* wr = wgt + ((size_t)(ky * KH + kx) * A.Cin + c) * A.w_ld + A.m_off;   // wave-uniform, noalias -> s_load
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            const float wv = wr[m];
+                            acc[0][m] = fmaf(xw[ky][kx], wv, acc[0][m]);
+                            acc[1][m] = fmaf(xw[ky][kx + 1], wv, acc[1][m]);
+                        }
+                    }
+            } else {   // A_UPF: 2x2 conv over the nearest-upsampled tensor; low-res window 2 x 2
+                float xl[2][2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int lr = (ty + r) >> 1;                  // rows (ty, ty+1) >> 1
+                    xl[r][0] = plane[lr * IWP + tx]; xl[r][1] = plane[lr * IWP + tx + 1];
+                }
+#pragma unroll
+                for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 2; ++kx) {
+                        const float* wr = wgt + ((size_t)(ky * 2 + kx) * A.Cin + c) * A.w_ld + A.m_off;
+                        // pixel p = 2*tx + p reads up-sampled column (2*tx + p + kx) >> 1 = tx + ((p + kx) >> 1)
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            const float wv = wr[m];
+                            acc[0][m] = fmaf(xl[ky][kx >> 1], wv, acc[0][m]);
+                            acc[1][m] = fmaf(xl[ky][(1 + kx) >> 1], wv, acc[1][m]);
+                        }
+                    }
+            }
+        }
+
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const bool valid = rowok && x + p < A.Wo;
+            const size_t pix = valid ? ((size_t)b * A.Ho + y) * A.Wo + x + p : 0;
+            float v[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) v[m] = acc[p][m];
+            if constexpr (EPI == EPI_FWD) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) { const float u = valid ? v[m] : 0.f; s1[m] += u; s2[m] += u * u; }
+            } else if constexpr (EPI == EPI_MASK) {
+                const float zz[M] = {zq[p][0].x, zq[p][0].y, zq[p][0].z, zq[p][0].w, zq[p][1].x, zq[p][1].y, zq[p][1].z, zq[p][1].w};
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float yv = fmaf(A.bnin[BN_A * M + m], zz[m], A.bnin[BN_B * M + m]);
+                    float gv = v[m];
+                    if (A.drop_out) gv *= drop_mul(A.drop, (uint32_t)(pix * M + m));
+                    gv = (valid && yv > 0.f) ? gv : 0.f;
+                    const float xh = (zz[m] - A.bnin[BN_MEAN * M + m]) * A.bnin[BN_RSTD * M + m];
+                    v[m] = gv; s1[m] += gv; s2[m] += gv * xh;
+                }
+            }
+            if (valid) {
+                st4(outp + pix * M, make_float4(v[0], v[1], v[2], v[3]));
+                st4(outp + pix * M + 4, make_float4(v[4], v[5], v[6], v[7]));
+            }
+        }
+    }
+    if constexpr (EPI != EPI_RAW) {
+        if (A.part) {
+            float* out = A.part + (size_t)blockIdx.x * (2 * M);
+            block_reduce_store<M>(s1, red, out, M);
+            block_reduce_store<M>(s2, red, out + M, M);
+        }
+    }
+}
+
+}  // namespace oct

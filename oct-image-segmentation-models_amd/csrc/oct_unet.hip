@@ -14,12 +14,14 @@
 #include "kernels_fwd.hpp"
 #include "kernels_igemm.hpp"
 #include "kernels_dw.hpp"
+#include "kernels_thin.hpp"
 
 using namespace oct;
 
 namespace {
 
 thread_local std::string g_err;
+int g_thin_min_tiles = 2048;      // pixel tiles from which 8-channel layers use the VALU thin kernel
 int g_persist_min_tiles = 2048;   // pixel tiles from which thin single-chunk convs use the persistent pipelined kernel
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -293,10 +295,27 @@ int launch_igemm_p(IgemmArgs a, int B, hipStream_t s, const char* layer, double 
     return 0;
 }
 
+// VALU kernel for 8-output-channel layers (see kernels_thin.hpp)
+template <int KH, int AMODE, int EPI>
+int launch_thin8(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+    a.tiles_x = cdiv(a.Wo, 64); a.tiles = a.tiles_x * cdiv(a.Ho, 8); a.total_tiles = B * a.tiles;
+    const int nblk = std::min(a.total_tiles, 1536);
+    char nm[48]; snprintf(nm, sizeof nm, "conv_thin8_k<%d,%d,%d,%d>", KH, AMODE, EPI, a.Cin <= 8 ? 8 : 16);
+    ProfScope ps(s, nm, layer, flops, bytes);
+    if (a.Cin <= 8) conv_thin8_k<KH, AMODE, EPI, 8><<<nblk, kBlock, 0, s>>>(a, a.w, a.out);
+    else conv_thin8_k<KH, AMODE, EPI, 16><<<nblk, kBlock, 0, s>>>(a, a.w, a.out);
+    HIP_OK(hipGetLastError());
+    *rows = nblk;
+    return 0;
+}
+
 template <int KH, int AMODE, int EPI>
 int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
     auto blocks = [&](int th, int mb) { return (long)B * cdiv(a.Ho, th) * cdiv(a.Wo, 32) * cdiv(a.Mout, mb); };
     if constexpr (AMODE != A_DOWN2) {
+        // 8 output channels: a 16-row MFMA tile would be half padding -> VALU kernel (same f32 peak, no padding)
+        if (a.Mout == 8 && a.Cin <= 16 && blocks(8, 16) >= g_thin_min_tiles)
+            return launch_thin8<KH, AMODE, EPI>(a, B, s, layer, flops, bytes, rows);
         // thin single-chunk layers with plenty of pixel tiles: persistent software-pipelined kernel
         if (a.Cin <= 16 && a.Mout <= 16 && blocks(8, 16) >= g_persist_min_tiles) {
             if (a.Cin <= 8) return launch_igemm_p<16, KH, AMODE, EPI, 8, 16, 4, 8>(a, B, s, layer, flops, bytes, rows);
@@ -839,6 +858,7 @@ int oct_unet_profile_end(oct_unet* h, oct_profile_entry* out, int max_entries, i
 int oct_set_option(const char* name, int value) {
     if (!name) return fail(-1, "null option name");
     if (!strcmp(name, "igemm_persistent_min_tiles")) { g_persist_min_tiles = value < 1 ? 1 : value; return 0; }
+    if (!strcmp(name, "thin8_min_tiles")) { g_thin_min_tiles = value < 1 ? 1 : value; return 0; }
     return fail(-1, std::string("unknown option: ") + name);
 }
 

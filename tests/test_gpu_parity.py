@@ -53,14 +53,16 @@ MARGIN_SEED = {CASES[0]: 97, CASES[1]: 13, CASES[2]: 28, CASES[3]: 75}
 DROP_STEP = 3
 
 
-@pytest.fixture(params=["tile_per_block", "persistent"])
+@pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu"])
 def variant(request):
     """Run the same verified inputs through both conv kernel variants for thin layers (the persistent
     software-pipelined one is otherwise only chosen on large grids)."""
     from oct_image_segmentation_models_amd import _hip
     _hip.set_option("igemm_persistent_min_tiles", 1 if request.param == "persistent" else 1 << 30)
+    _hip.set_option("thin8_min_tiles", 1 if request.param == "thin8_valu" else 1 << 30)
     yield request.param
     _hip.set_option("igemm_persistent_min_tiles", 2048)
+    _hip.set_option("thin8_min_tiles", 2048)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -236,7 +238,8 @@ def test_full_size_properties_config2():
     singles = []
     for i in range(B):
         pi, _ = eng.forward(x[i:i + 1].contiguous(), training=False, labels=lab[i:i + 1].contiguous())
-        assert torch.equal(pi[0], probs[i])
+        # kernel variants are chosen by grid size, so batch-1 and batch-4 runs may differ in the last bits
+        assert torch.allclose(pi[0], probs[i], atol=1e-6, rtol=0)
         singles.append(eng.loss_dice().cpu().numpy())
     assert abs(np.mean([s[0] for s in singles]) - l_all[0]) < 1e-6
     eng.forward(x, training=True, labels=lab, want_probs=False)
