@@ -422,6 +422,32 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_k(const float* __restr
     }
 }
 
+// all layers' slab sums in ONE launch (the per-layer launches are latency-bound, ~20 us each): descriptor table by value
+struct ReduceAllArgs {
+    static constexpr int MAXL = 40;
+    int n;
+    struct Entry { const float* part; float* dw; float* db; int npb, jw; unsigned stride, wsize, blk_start; } L[MAXL];
+};
+
+__global__ __launch_bounds__(kBlock) void reduce_all_k(const ReduceAllArgs A) {
+    __shared__ double sh[kBlock];
+    int d = 0;
+    while (d + 1 < A.n && blockIdx.x >= A.L[d + 1].blk_start) ++d;
+    const ReduceAllArgs::Entry E = A.L[d];
+    const int jw = E.jw, nq = kBlock / jw, col = threadIdx.x % jw, q = threadIdx.x / jw;
+    const size_t j = (size_t)(blockIdx.x - E.blk_start) * jw + col;
+    double s = 0;
+    if (j < E.stride)
+        for (int p = q; p < E.npb; p += nq) s += E.part[(size_t)p * E.stride + j];
+    sh[q * jw + col] = s;
+    __syncthreads();
+    if (q == 0 && j < E.stride) {
+        double t = 0;
+        for (int k = 0; k < nq; ++k) t += sh[k * jw + col];
+        if (j < E.wsize) E.dw[j] = (float)t; else E.db[j - E.wsize] = (float)t;
+    }
+}
+
 // ---- optimizers (Keras formulations) ----------------------------------------------------
 __global__ __launch_bounds__(kBlock) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                 float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps) {

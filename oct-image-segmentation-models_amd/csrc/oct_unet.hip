@@ -64,6 +64,7 @@ struct Layer {
     size_t w_off, b_off, gamma_off, beta_off, mm_off, mv_off;
     // workspace (device) pointers
     float* z = nullptr; float* g = nullptr; float* bn = nullptr;
+    float* dwp = nullptr;  // this layer's dW slabs [npb][kh*kw*cin*cout + cout]
     float* wt = nullptr;   // backward-data weights: transposed+flipped 3x3, or effective 3x3 of an up-conv (9*cin*cout)
 };
 
@@ -88,6 +89,8 @@ int check_cfg(const oct_unet_cfg* c) {
     if (c->max_batch < 1) return fail(-1, "max_batch must be >= 1");
     if (c->dtype != 0) return fail(-2, "dtype: only 0 (f32) is implemented");
     if (!(c->dropout_rate >= 0.f && c->dropout_rate < 1.f)) return fail(-1, "dropout_rate must be in [0,1)");
+    if (c->pool_layers * (2 * c->conv_layers + 1) + c->conv_layers + 1 > ReduceAllArgs::MAXL)
+        return fail(-1, "too many conv layers (pool_layers*(2*conv_layers+1)+conv_layers+1 must be <= 40)");
     if ((size_t)c->max_batch * c->H * c->W * (size_t)(c->start_neurons << c->pool_layers) >= (1ull << 32))
         return fail(-1, "tensor too large for 32-bit dropout indexing");
     return 0;
@@ -170,7 +173,7 @@ struct oct_unet {
     float* params; float* grads; float* state;
     std::vector<float*> pooled, gpooled;   // per encoder level
     float* stat_part = nullptr;            // BN statistic partials (fwd and bwd share it: stream-ordered)
-    float* dw_part = nullptr;
+    ReduceAllArgs red{};                   // filled while backward runs; one reduce launch at the end
     float* dice_part = nullptr; double* dice_bc = nullptr; float* loss4 = nullptr;
     WtDesc* wt_descs = nullptr; int n_wt = 0; unsigned wt_total = 0;
     unsigned long long drop_step = 0; int drop_advance = 0;
@@ -199,8 +202,10 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
         stat_max = std::max(stat_max, B * cdiv(l.H, 2) * cdiv(l.W, kTileX) * 2 * (size_t)std::max(l.cout, l.cin));
         if (c.training) {
             const size_t wsz = (size_t)l.kh * l.kw * l.cin * l.cout + l.cout;
-            dw_max = std::max(dw_max, (size_t)dw_plan(l, c.max_batch).npb * wsz);
-            if (l.src == SRC_HEAD) dw_max = std::max(dw_max, (size_t)(2048 + c.max_batch) * wsz);
+            const size_t rows = l.src == SRC_HEAD ? (size_t)(2048 + c.max_batch) : (size_t)dw_plan(l, c.max_batch).npb;
+            float* dwp = (float*)take(rows * wsz * 4);
+            if (base) l.dwp = dwp;
+            dw_max = 0;
         }
     }
     for (int i = 0; i < pl.P; ++i) {
@@ -212,13 +217,12 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
     const int nblk_head = cdiv(c.H * c.W, kBlock);
     stat_max = std::max(stat_max, B * nblk_head * 2 * (size_t)c.start_neurons);
     float* sp = (float*)take(stat_max * 4);
-    float* dwp = c.training ? (float*)take(dw_max * 4) : nullptr;
     float* dp = (float*)take(B * nblk_head * 64 * 4);
     double* bc = (double*)take((B * 8 * 2 + 2) * 8);
     float* l4 = (float*)take(4 * 4);
     WtDesc* wd = c.training ? (WtDesc*)take(pl.L.size() * sizeof(WtDesc)) : nullptr;
     if (h) h->wt_descs = wd;
-    if (h) { h->stat_part = sp; h->dw_part = dwp; h->dice_part = dp; h->dice_bc = bc; h->loss4 = l4; }
+    if (h) { h->stat_part = sp; h->dice_part = dp; h->dice_bc = bc; h->loss4 = l4; }
     return off;
 }
 
@@ -492,6 +496,31 @@ int launch_dw(const ConvBwdWArgs& a, int ci_t, int co_t, hipStream_t s, const ch
     return fail(-3, "dW: unsupported channel chunking");
 }
 
+// register a layer's slabs for the single end-of-backward reduce launch
+void queue_reduce(oct_unet* h, const Layer& l, int npb) {
+    ReduceAllArgs& R = h->red;
+    ReduceAllArgs::Entry& e = R.L[R.n];
+    e.part = l.dwp; e.dw = h->grads + l.w_off; e.db = h->grads + l.b_off; e.npb = npb;
+    e.wsize = (unsigned)((size_t)l.kh * l.kw * l.cin * l.cout); e.stride = e.wsize + l.cout;
+    e.jw = e.stride < 16384 ? 16 : 64;
+    e.blk_start = R.n ? R.L[R.n - 1].blk_start + cdiv((int)R.L[R.n - 1].stride, R.L[R.n - 1].jw) : 0;
+    ++R.n;
+}
+
+int flush_reduce(oct_unet* h, hipStream_t s) {
+    ReduceAllArgs& R = h->red;
+    if (!R.n) return 0;
+    const ReduceAllArgs::Entry& last = R.L[R.n - 1];
+    const unsigned blocks = last.blk_start + cdiv((int)last.stride, last.jw);
+    double bytes = 0;
+    for (int i = 0; i < R.n; ++i) bytes += (double)R.L[i].npb * R.L[i].stride * 4;
+    ProfScope ps(s, "reduce_all_k", "all", 0, bytes);
+    reduce_all_k<<<blocks, kBlock, 0, s>>>(R);
+    HIP_OK(hipGetLastError());
+    R.n = 0;
+    return 0;
+}
+
 int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const float* dz, int B, hipStream_t s) {
     const Layer& l = h->plan.L[li];
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
@@ -499,7 +528,7 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const fl
     ConvBwdWArgs a{};
     a.x0 = sd.x0; a.ab0 = sd.ab0; a.C0 = sd.C0; a.x1 = sd.x1; a.ab1 = sd.ab1; a.C1 = sd.C1;
     a.flags = sd.flags | (l.drop_in ? F_DROP : 0);
-    a.dz = dz; a.part = h->dw_part;
+    a.dz = dz; a.part = l.dwp;
     a.B = B; a.H = l.H; a.W = l.W; a.Cin = l.cin; a.Cout = l.cout;
     a.tiles_x = cdiv(l.W, kTileX); a.tiles = p.tiles; a.total_tiles = B * a.tiles; a.npb = p.npb;
     a.drop = make_drop(h);
@@ -523,13 +552,7 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const fl
         HIP_OK(hipGetLastError());
     }
     if (rc) return rc;
-    const size_t wsize = (size_t)l.kh * l.kw * l.cin * l.cout, stride = wsize + l.cout;
-    ProfScope ps(s, "reduce_partials_k", l.name, 0, (double)a.npb * stride * 4);
-    if (stride < 16384)   // small slabs: 16 columns x 16 slab slices per block, so the sum is parallel over slabs too
-        reduce_partials_k<16><<<(int)((stride + 15) / 16), kBlock, 0, s>>>(h->dw_part, a.npb, stride, wsize, h->grads + l.w_off, h->grads + l.b_off);
-    else
-        reduce_partials_k<64><<<(int)((stride + 63) / 64), kBlock, 0, s>>>(h->dw_part, a.npb, stride, wsize, h->grads + l.w_off, h->grads + l.b_off);
-    HIP_OK(hipGetLastError());
+    queue_reduce(h, l, a.npb);
     return 0;
 }
 
@@ -556,7 +579,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     // head: dlogits, masked gradient of the last block + its statistics
     HeadBwdArgs hb{};
     hb.z = last.z; hb.bn = last.bn; hb.w = h->params + hd.w_off; hb.bias = h->params + hd.b_off;
-    hb.labels = labels; hb.bc = h->dice_bc; hb.g = last.g; hb.part = h->stat_part; hb.wpart = h->dw_part;
+    hb.labels = labels; hb.bc = h->dice_bc; hb.g = last.g; hb.part = h->stat_part; hb.wpart = hd.dwp;
     hb.HW = hd.H * hd.W; hb.nblk = head_nblk(hb.HW, B); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale;
     {   // backward-data weights of every block for this step's parameters (one launch)
         ProfScope ps(s, "prep_wt_k", "all", 0, (double)h->wt_total * 8);
@@ -566,13 +589,8 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     int rc = DISPATCH_C(launch_head_bwd, h->cfg.n_cls, hb, hd.cin, B, s);
     if (rc) return rc;
     int pending_nblk = B * hb.nblk;           // number of stat partial rows waiting for block (li-1)
-    {   // head kernel/bias gradient: sum the per-block rows written by head_bwd_k
-        const size_t wsize = (size_t)hd.cin * hd.cout, stride = wsize + hd.cout;
-        ProfScope ps(s, "reduce_partials_k", "head", 0, (double)pending_nblk * stride * 4);
-        reduce_partials_k<16><<<(int)((stride + 15) / 16), kBlock, 0, s>>>(h->dw_part, pending_nblk, stride, wsize,
-                                                                          h->grads + hd.w_off, h->grads + hd.b_off);
-        HIP_OK(hipGetLastError());
-    }
+    h->red.n = 0;
+    queue_reduce(h, hd, pending_nblk);   // head kernel/bias gradient rows written by head_bwd_k
 
     for (int li = nl - 2; li >= 0; --li) {
         Layer& l = pl.L[li];
@@ -643,7 +661,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         }
         if (rc) return rc;
     }
-    return 0;
+    return flush_reduce(h, s);
 }
 
 }  // namespace
