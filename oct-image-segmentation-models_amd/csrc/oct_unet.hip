@@ -161,7 +161,10 @@ DwPlan dw_plan(const Layer& l, int B) {
     p.chunks = cdiv(l.cin, p.cic) * cdiv(l.cout, p.coc);
     p.tiles = cdiv(l.H, p.th) * cdiv(l.W, kTileX);
     const int total = B * p.tiles;
-    p.npb = std::max(1, std::min(total, cdiv(768, p.chunks)));
+    // one full round of resident blocks (no half-empty tail round): the wide kernel fits 2 blocks per CU (registers),
+    // for the thin one 768 blocks measured best
+    const int target = p.kind == 32 ? 512 : 768;
+    p.npb = std::max(1, std::min(total, cdiv(target, p.chunks)));
     return p;
 }
 
