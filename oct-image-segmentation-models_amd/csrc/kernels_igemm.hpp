@@ -177,41 +177,73 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
         boff[nt] = AMODE == A_NORMAL ? r * IW + xs : (AMODE == A_UPF ? 0 : (2 * r) * IW + 2 * xs);
     }
 
-    for (int c0 = 0; c0 < A.Cin; c0 += KC) {
-        __syncthreads();   // previous chunk fully consumed
-        // ---- stage the input chunk: NHWC global (float4 = 4 channels of a pixel) -> planar LDS, transform on load ----
-        for (int e = tid; e < (KC / 4) * IH * IW; e += kBlock) {
+    // K-chunk pipeline: the global loads of chunk c+1 (input tile + weight tile) are issued into registers before
+    // the MFMA sweep of chunk c and written to LDS after it
+    constexpr int NPI = ((KC / 4) * IH * IW + kBlock - 1) / kBlock;
+    constexpr int NPW = (TAPS * KC * (MB / 4) + kBlock - 1) / kBlock;
+    float4 pin[NPI], pw[NPW];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < NPI; ++k) {
+            const int e = tid + k * kBlock;
             const int q = e % (KC / 4), p = e / (KC / 4), lx = p % IW, ly = p / IW;
             const int gy = iy0 + ly, gx = ix0 + lx, c = c0 + 4 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
+            pin[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < (KC / 4) * IH * IW && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
                 const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
-                const float* src = A.x0; const float* ab = A.ab0; int C = A.C0, cc = c;
-                if ((A.flags & F_TWO) && c >= A.C0) { src = A.x1; ab = A.ab1; C = A.C1; cc = c - A.C0; }
-                v = ld4(src + pix * C + cc);
-                if (A.flags & F_AFF) {
-                    const float4 a = ld4(ab + cc), bb = ld4(ab + C + cc);
-                    v.x = fmaxf(fmaf(a.x, v.x, bb.x), 0.f); v.y = fmaxf(fmaf(a.y, v.y, bb.y), 0.f);
-                    v.z = fmaxf(fmaf(a.z, v.z, bb.z), 0.f); v.w = fmaxf(fmaf(a.w, v.w, bb.w), 0.f);
-                }
-                if (A.flags & F_DROP) {
-                    const uint32_t el = (uint32_t)(pix * C + cc);
-                    v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
-                    v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
-                }
+                pin[k] = ld4(((A.flags & F_TWO) && c >= A.C0) ? A.x1 + pix * A.C1 + (c - A.C0) : A.x0 + pix * A.C0 + c);
             }
-            float* d = Is + (4 * q) * PLANE + ly * IW + lx;
-            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
         }
-        // ---- stage the weight chunk [tap][kc][m] ----
-        for (int e = tid; e < TAPS * KC * (MB / 4); e += kBlock) {
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const int e = tid + k * kBlock;
             const int m4 = e % (MB / 4), r = e / (MB / 4), kc = r % KC, tap = r / KC;
             const int c = c0 + kc, m = m0 + 4 * m4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < A.Cin && m < A.Mout) v = ld4(A.w + ((size_t)tap * A.Cin + c) * A.w_ld + A.m_off + m);
-            st4(Ws + (tap * KC + kc) * MB + 4 * m4, v);
+            pw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < TAPS * KC * (MB / 4) && c < A.Cin && m < A.Mout)
+                pw[k] = ld4(A.w + ((size_t)tap * A.Cin + c) * A.w_ld + A.m_off + m);
         }
+    };
+    auto store_chunk = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < NPI; ++k) {
+            const int e = tid + k * kBlock;
+            if (e < (KC / 4) * IH * IW) {
+                const int q = e % (KC / 4), p = e / (KC / 4), lx = p % IW, ly = p / IW;
+                const int gy = iy0 + ly, gx = ix0 + lx, c = c0 + 4 * q;
+                float4 v = pin[k];
+                if (gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
+                    const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
+                    const float* ab = A.ab0; int C = A.C0, cc = c;
+                    if ((A.flags & F_TWO) && c >= A.C0) { ab = A.ab1; C = A.C1; cc = c - A.C0; }
+                    if (A.flags & F_AFF) {
+                        const float4 a = ld4(ab + cc), bb = ld4(ab + C + cc);
+                        v.x = fmaxf(fmaf(a.x, v.x, bb.x), 0.f); v.y = fmaxf(fmaf(a.y, v.y, bb.y), 0.f);
+                        v.z = fmaxf(fmaf(a.z, v.z, bb.z), 0.f); v.w = fmaxf(fmaf(a.w, v.w, bb.w), 0.f);
+                    }
+                    if (A.flags & F_DROP) {
+                        const uint32_t el = (uint32_t)(pix * C + cc);
+                        v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
+                        v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
+                    }
+                }
+                float* d = Is + (4 * q) * PLANE + ly * IW + lx;
+                d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const int e = tid + k * kBlock;
+            if (e < TAPS * KC * (MB / 4)) st4(Ws + (e / (MB / 4)) * MB + 4 * (e % (MB / 4)), pw[k]);
+        }
+    };
+
+    load_chunk(0);
+    for (int c0 = 0; c0 < A.Cin; c0 += KC) {
+        __syncthreads();   // previous chunk fully consumed
+        store_chunk(c0);
         __syncthreads();
+        if (c0 + KC < A.Cin) load_chunk(c0 + KC);
         // ---- MFMA over taps x k-steps (only the channels that exist: thin layers have Cin < KC) ----
         const int nks = (A.Cin - c0 < KC ? A.Cin - c0 : KC) / KS;
         if (nks == KC / KS) mfma_sweep<SHAPE, KH, AMODE, KC, MB, IW, PLANE, NPR, MTW, NTW, true>(Ws, Is, acc, boff, wn, wm, j, kk, nks);
