@@ -170,25 +170,40 @@ def main():
             k = by_k.setdefault(e["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             k["ms"] += e["total_ms"]; k["flops"] += e["flops"]; k["bytes"] += e["bytes"]; k["launches"] += e["launches"]
         total_ms = sum(k["ms"] for k in by_k.values())
-        name, dom = max(by_k.items(), key=lambda kv: kv[1]["ms"])
-        ai = dom["flops"] / max(dom["bytes"], 1.0)
-        avg_us = dom["ms"] / dom["launches"] * 1e3
-        if ai > PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
-            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_TFLOPS, 4)}
-        else:
-            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        def roof_of(k):
+            """achieved = ALGORITHMIC flops (or bytes) of the kernel's launches / their summed HIP-event duration"""
+            ai = k["flops"] / max(k["bytes"], 1.0)
+            if ai > PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+                ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+                return {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_F32_TFLOPS, 4)}
+            ach = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4)}
-        roof.update({"traffic": None, "kernel": name, "avg_launch_us": round(avg_us, 2),
+
+        name, dom = max(by_k.items(), key=lambda kv: kv[1]["ms"])
+        avg_us = dom["ms"] / dom["launches"] * 1e3
+        roof = roof_of(dom)
+        # HBM traffic of that kernel from the committed rocprofv3 --pmc passes of this same command (profiles/), per launch
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            key = name.replace("conv_igemm_k<", "conv_igemm_k<").split(">")[0]
+            for k, v in pmc.items():
+                if k.replace(" ", "").startswith(key.replace(" ", "")):
+                    traffic = round(v["hbm_bytes_per_launch"], 0)
+                    break
+        except (OSError, KeyError, ValueError):
+            traffic = None
+        roof.update({"traffic": traffic, "kernel": name, "avg_launch_us": round(avg_us, 2),
                      "launches_per_step": dom["launches"] // nprof,
                      "share_of_step_kernel_time": round(dom["ms"] / total_ms, 4),
                      "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
                      "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]})
         out["roofline"] = roof
-        top = sorted(by_k.items(), key=lambda kv: -kv[1]["ms"])[:8]
+        top = sorted(by_k.items(), key=lambda kv: -kv[1]["ms"])[:10]
         out["kernel_time_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in top}
+        out["roofline_top_kernels"] = {k: dict(roof_of(v), ms_per_step=round(v["ms"] / nprof, 4)) for k, v in top}
         # whole-step roofline context: SURVEY 8d algorithmic work per scan (10.27 GFLOP, 253 MB) vs step time
         out["step_vs_roofline"] = {"algorithmic_gflop_per_scan": 10.27, "algorithmic_mb_per_scan": 253.0,
                                    "roofline_us_per_scan": 73.2,

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Turns the outputs of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the committed artefacts under profiles/:
+
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `bench.py` (per-kernel calls / avg / total)
+  profiles/<tag>_pmc_traffic.json   per-kernel HBM traffic per launch from the separate --pmc FETCH_SIZE / WRITE_SIZE
+                                    passes: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE reports
+                                    half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section)
+  profiles/<tag>_bench.json         the bench line of the same run
+  profiles/<tag>_launch_table.json  per-(kernel, layer) HIP-event durations + algorithmic flops/bytes (library profiler)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    return name.replace("void oct::", "").replace("oct::", "").split("(")[0].replace(", ", ",")
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+for f in ("bench.json", "launch_table.json"):
+    shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
+
+traffic = collections.defaultdict(lambda: dict(launches=0, fetch_kb=0.0, write_kb=0.0))
+for counter, key in (("FETCH_SIZE", "fetch_kb"), ("WRITE_SIZE", "write_kb")):
+    f = glob.glob(os.path.join(src, f"pmc_{counter}", "*", "*_counter_collection.csv"))[0]
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter or "oct::" not in r["Kernel_Name"]:
+            continue
+        # only the per-rank-batch-32 training launches + batch-32 inference of this pass: all launches of the pass
+        t = traffic[short(r["Kernel_Name"])]
+        t[key] += float(r["Counter_Value"])
+        if counter == "FETCH_SIZE":
+            t["launches"] += 1
+out = {}
+for k, t in traffic.items():
+    n = max(t["launches"], 1)
+    out[k] = {"launches_in_pass": t["launches"],
+              "fetch_size_kb_per_launch": t["fetch_kb"] / n, "write_size_kb_per_launch": t["write_kb"] / n,
+              "hbm_bytes_per_launch": (2.0 * t["fetch_kb"] + t["write_kb"]) / n * 1024.0}
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1 "
+                   "--infer-batch 32`; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction); "
+                   "averages over all launches of a kernel instantiation in the pass (all layers it serves)",
+           "kernels": out}, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+
+rows = list(csv.DictReader(open(stats)))
+print(f"{'kernel':52s} {'calls':>6s} {'avg_us':>9s} {'total_ms':>9s} {'%':>6s} {'HBM MB/launch':>14s}")
+for r in rows[:24]:
+    k = short(r["Name"])
+    mb = out.get(k, {}).get("hbm_bytes_per_launch", 0) / 1e6
+    print(f"{k[:52]:52s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:9.1f} {float(r['TotalDurationNs'])/1e6:9.2f} "
+          f"{float(r['Percentage']):6.1f} {mb:14.1f}")
