@@ -172,6 +172,23 @@ __global__ void bn_infer_coeffs_k(const float* gamma, const float* beta, const f
     bn[BN_RSTD * C + c] = 1.f / sqrtf(mv[c] + eps);
 }
 
+// all blocks at once (descriptor table by value): grid = number of BN blocks
+struct BnInferAll {
+    static constexpr int MAXL = 40;
+    int n;
+    struct Entry { const float* gamma; const float* beta; const float* mm; const float* mv; float* bn; int C; } L[MAXL];
+};
+__global__ void bn_infer_all_k(const BnInferAll A, float eps) {
+    const BnInferAll::Entry E = A.L[blockIdx.x];
+    for (int c = threadIdx.x; c < E.C; c += blockDim.x) {
+        const float rstd = 1.f / sqrtf(E.mv[c] + eps), a = E.gamma[c] * rstd;
+        E.bn[BN_A * E.C + c] = a;
+        E.bn[BN_B * E.C + c] = E.beta[c] - E.mm[c] * a;
+        E.bn[BN_MEAN * E.C + c] = E.mm[c];
+        E.bn[BN_RSTD * E.C + c] = rstd;
+    }
+}
+
 // ---- max-pool 2x2 with BN+ReLU fused on load: p = max over window of relu(a*z+b) -------------------------
 __global__ __launch_bounds__(kBlock) void pool_fwd_k(const float* __restrict__ z, const float* __restrict__ ab,
                                                     float* __restrict__ p, int B, int H, int W, int C) {

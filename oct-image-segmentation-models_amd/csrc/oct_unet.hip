@@ -91,8 +91,12 @@ int check_cfg(const oct_unet_cfg* c) {
     if (!(c->dropout_rate >= 0.f && c->dropout_rate < 1.f)) return fail(-1, "dropout_rate must be in [0,1)");
     if (c->pool_layers * (2 * c->conv_layers + 1) + c->conv_layers + 1 > ReduceAllArgs::MAXL)
         return fail(-1, "too many conv layers (pool_layers*(2*conv_layers+1)+conv_layers+1 must be <= 40)");
-    if ((size_t)c->max_batch * c->H * c->W * (size_t)(c->start_neurons << c->pool_layers) >= (1ull << 32))
-        return fail(-1, "tensor too large for 32-bit dropout indexing");
+    // the dropped tensor is the bottleneck output: (H/2^P, W/2^P, start_neurons*2^P)
+    if ((size_t)c->max_batch * (c->H >> c->pool_layers) * (c->W >> c->pool_layers) *
+            (size_t)(c->start_neurons << c->pool_layers) >= (1ull << 32))
+        return fail(-1, "bottleneck tensor too large for 32-bit dropout indexing");
+    if ((size_t)c->max_batch * c->H * c->W * (size_t)(2 * c->start_neurons) >= (1ull << 31))
+        return fail(-1, "max_batch * H * W too large for the 32-bit element indexing used inside a layer");
     return 0;
 }
 
@@ -451,13 +455,16 @@ int dice_n(int C) { return 5 * C <= 16 ? 16 : (5 * C <= 32 ? 32 : 64); }
 int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, const oct_unet_io* io, hipStream_t s) {
     Plan& pl = h->plan;
     const int nl = (int)pl.L.size();
-    if (!training) {  // (a, b) from moving statistics
-        ProfScope ps(s, "bn_infer_coeffs_k", "all", 0, (double)pl.n_state * 4 * 3);
+    if (!training) {  // (a, b) of every block from the moving statistics: one launch
+        ProfScope ps(s, "bn_infer_all_k", "all", 0, (double)pl.n_state * 4 * 3);
+        BnInferAll ia{};
         for (auto& l : pl.L)
             if (l.has_bn) {
-                bn_infer_coeffs_k<<<cdiv(l.cout, 64), 64, 0, s>>>(h->params + l.gamma_off, h->params + l.beta_off,
-                                                                  h->state + l.mm_off, h->state + l.mv_off, l.bn, l.cout, h->cfg.bn_eps);
+                auto& e = ia.L[ia.n++];
+                e.gamma = h->params + l.gamma_off; e.beta = h->params + l.beta_off;
+                e.mm = h->state + l.mm_off; e.mv = h->state + l.mv_off; e.bn = l.bn; e.C = l.cout;
             }
+        bn_infer_all_k<<<ia.n, 128, 0, s>>>(ia, h->cfg.bn_eps);
         HIP_OK(hipGetLastError());
     }
     for (int li = 0; li < nl - 1; ++li) {

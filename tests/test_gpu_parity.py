@@ -246,3 +246,30 @@ def test_full_size_properties_config2():
     eng.loss_dice(); eng.backward(lab)
     g = eng.grads.cpu().numpy()
     assert np.isfinite(g).all() and np.abs(g).max() > 1e-6
+
+
+def test_config3_shape_runs_in_fp32():
+    """BASELINE configs[2] shape (512x1024x1, pool_layers=5) in the implemented fp32 mode (bf16 storage is a
+    reserved, rejected dtype): a few training steps + inference at a reduced batch; finite, normalised, learning."""
+    import ctypes
+    from oct_image_segmentation_models_amd import _hip
+    from oct_image_segmentation_models_amd.engine import UNetEngine, make_cfg
+    B, H, W, C = 2, 512, 1024, 3
+    # the full configuration (batch 64) is accepted by the config check
+    make_cfg(input_channels=1, num_classes=3, image_height=H, image_width=W, pool_layers=5, max_batch=64, training=True)
+    eng = UNetEngine(device="cuda:0", input_channels=1, num_classes=C, image_height=H, image_width=W, pool_layers=5,
+                     max_batch=B, training=True, seed=3)
+    assert eng.n_params == 1948267
+    images, labels = data(B, H, W, C, seed=4)
+    x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+    losses = []
+    for _ in range(8):
+        eng.forward(x, training=True, labels=lab, want_probs=False)
+        losses.append(eng.loss_dice()); eng.backward(lab); eng.adam_step(lr=2e-3)
+    losses = torch.stack(losses).cpu().numpy()
+    assert np.isfinite(losses).all() and losses[-1, 0] < losses[0, 0]
+    probs, am = eng.forward(x, training=False, want_argmax=True)
+    assert torch.allclose(probs.sum(-1), torch.ones_like(probs[..., 0]), atol=1e-5) and torch.equal(am.long(), probs.argmax(-1))
+    cfg = make_cfg(input_channels=1, num_classes=3, image_height=H, image_width=W, pool_layers=5)
+    cfg.dtype = 1
+    assert _hip.lib().oct_unet_cfg_check(ctypes.byref(cfg)) != 0 and b"f32" in _hip.lib().oct_last_error()
