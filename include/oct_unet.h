@@ -130,6 +130,11 @@ typedef struct oct_profile_entry {
 int oct_unet_profile_begin(oct_unet* h);
 int oct_unet_profile_end(oct_unet* h, oct_profile_entry* out, int max_entries, int* n_out);
 
+/* ---- post-step on device: (B,H,W) u8 class maps -> (B, n_cls-1, H, W) u8 boundary maps, exactly
+ * convert_predictions_to_maps_semantic(one_hot(argmax)) of the reference (common/utils.py:115-168) ---- */
+int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int n_cls, int bg_ilm, int bg_csi,
+                      unsigned char* maps_dev, oct_stream_t stream);
+
 /* ---- tuning knobs (process-wide; results do not depend on them, only which kernel variant runs) ----
  *   "igemm_persistent_min_tiles" (default 2048): number of pixel tiles from which thin single-chunk convs use the
  *   persistent software-pipelined kernel instead of the one-tile-per-block kernel.

@@ -71,6 +71,7 @@ SYMBOLS = [
     ("oct_unet_graph_launch", C.c_int, [C.c_void_p, C.c_void_p]),
     ("oct_unet_profile_begin", C.c_int, [C.c_void_p]),
     ("oct_unet_profile_end", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _P(C.c_int)]),
+    ("oct_boundary_maps", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("oct_set_option", C.c_int, [C.c_char_p, C.c_int]),
     ("oct_unet_debug_activation", C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
     ("oct_last_error", C.c_char_p, []),

@@ -339,6 +339,47 @@ __global__ __launch_bounds__(kBlock) void dice_finalize_k(const DiceFinArgs A) {
     }
 }
 
+// ---- post-step on device: class map -> boundary maps, the reference's
+// convert_predictions_to_maps_semantic (common/utils.py:115-168) on the one-hot of the arg-max:
+//   cur = [label == k],  g = 2*max(+-gradient_rows(cur), 0)  (np.gradient: central differences, one-sided at the
+//   edges),  out = uint8(255 * max(g[r] - g[(r+1) mod H], 0))   -- exact in small integers.
+// labels (B,H,W) u8 -> maps (B, C-1, H, W) u8.  One thread per (b, r, c); adjacent threads walk adjacent columns.
+__global__ __launch_bounds__(kBlock) void boundary_maps_k(const unsigned char* __restrict__ lab, unsigned char* __restrict__ out,
+                                                         int B, int H, int W, int C, int bg_ilm, int bg_csi) {
+    const size_t n = (size_t)B * H * W;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const int c = (int)(i % W); size_t t = i / W;
+        const int r = (int)(t % H), b = (int)(t / H);
+        const unsigned char* col = lab + (size_t)b * H * W + c;
+        auto L = [&](int rr) { return (int)col[(size_t)rr * W]; };
+        // rows needed for g[r] and g[r1]: r-1, r, r+1 and r1-1, r1, r1+1 with r1 = (r+1) mod H
+        const int r1 = r + 1 == H ? 0 : r + 1;
+        int lv[6];
+        const int rows[6] = {r > 0 ? r - 1 : 0, r, r + 1 < H ? r + 1 : H - 1, r1 > 0 ? r1 - 1 : 0, r1, r1 + 1 < H ? r1 + 1 : H - 1};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) lv[k] = L(rows[k]);
+        for (int m = 1; m < C; ++m) {
+            const bool flip = (m == 1 && bg_ilm) || (m == C - 1 && bg_csi);
+            const int k = flip ? m - 1 : m;
+            auto grad2 = [&](int rr, int lo, int mid, int hi) {   // 2 * np.gradient at row rr, times 2 again = 4*grad
+                // interior: (hi - lo)/2 ; first row: (hi - mid) ; last row: (mid - lo)   -> in units of 1/2
+                int d2;
+                if (H == 1) d2 = 0;
+                else if (rr == 0) d2 = 2 * ((hi == k) - (mid == k));
+                else if (rr == H - 1) d2 = 2 * ((mid == k) - (lo == k));
+                else d2 = (hi == k) - (lo == k);
+                if (flip) d2 = -d2;
+                return d2 > 0 ? d2 : 0;                           // = max(grad,0)*2 expressed in units of 1/2... see below
+            };
+            // g = 2*max(grad,0) with grad in {0, 1/2, 1}: g in {0, 1, 2}; grad2() returns 2*max(grad,0) = g exactly
+            const int g0 = grad2(r, lv[0], lv[1], lv[2]);
+            const int g1 = grad2(r1, lv[3], lv[4], lv[5]);
+            int v = g0 - g1; v = v > 0 ? v : 0;
+            out[(((size_t)b * (C - 1) + (m - 1)) * H + r) * W + c] = (unsigned char)((v * 255) & 255);   // numpy's float->uint8 cast of 510 wraps to 254
+        }
+    }
+}
+
 // dropout keep-mask dump for parity tests
 __global__ void dropout_mask_k(unsigned char* out, size_t n, DropCfg d) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

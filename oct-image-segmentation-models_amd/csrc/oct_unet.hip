@@ -883,6 +883,16 @@ int oct_unet_profile_end(oct_unet* h, oct_profile_entry* out, int max_entries, i
     return 0;
 }
 
+int oct_boundary_maps(const unsigned char* labels, int B, int H, int W, int n_cls, int bg_ilm, int bg_csi,
+                      unsigned char* maps, oct_stream_t stream) {
+    if (!labels || !maps || B < 1 || H < 1 || W < 1 || n_cls < 2) return fail(-1, "boundary_maps: bad arguments");
+    const size_t n = (size_t)B * H * W;
+    boundary_maps_k<<<(int)std::min<size_t>((n + kBlock - 1) / kBlock, 8192), kBlock, 0, (hipStream_t)stream>>>(
+        labels, maps, B, H, W, n_cls, bg_ilm, bg_csi);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int oct_set_option(const char* name, int value) {
     if (!name) return fail(-1, "null option name");
     if (!strcmp(name, "igemm_persistent_min_tiles")) { g_persist_min_tiles = value < 1 ? 1 : value; return 0; }

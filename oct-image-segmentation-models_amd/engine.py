@@ -235,6 +235,18 @@ class UNetEngine:
         with torch.cuda.device(self.device):
             _hip.check(_hip.lib().oct_unet_graph_launch(self._h, self._stream()), "oct_unet_graph_launch")
 
+    # ---- post-step on device ---------------------------------------------------------------------
+    def boundary_maps(self, labels: torch.Tensor, bg_ilm: bool = True, bg_csi: bool = False) -> torch.Tensor:
+        """(B,H,W) uint8 class maps (e.g. the arg-max output) -> (B, num_classes-1, H, W) uint8 boundary maps."""
+        if labels.device != self.device or labels.dtype != torch.uint8 or not labels.is_contiguous() or labels.dim() != 3:
+            raise OctError("labels must be a contiguous uint8 (B,H,W) tensor on the engine's device")
+        B, H, W = labels.shape
+        out = torch.empty((B, self.cfg.n_cls - 1, H, W), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _hip.check(_hip.lib().oct_boundary_maps(labels.data_ptr(), B, H, W, self.cfg.n_cls, int(bg_ilm), int(bg_csi),
+                                                    out.data_ptr(), self._stream()), "oct_boundary_maps")
+        return out
+
     # ---- weights exchange --------------------------------------------------------------------------
     def get_weights(self) -> List[np.ndarray]:
         """Keras ``get_weights()`` order: Conv2D [kernel HWIO, bias]; BN [gamma, beta, moving_mean, moving_var]."""

@@ -107,7 +107,8 @@ def evaluate_model(eval_params: EvaluationParameters) -> List[EvaluationOutput]:
         b1 = min(b0 + bs, hi)
         start_predict_time = time.time()
         # raw uint8 images go to the device; the /255 preprocessing is fused into the first conv's load
-        label_maps = eval_params.loaded_model.predict_labels(eval_images[b0:b1], batch_size=bs)
+        label_maps, dev_maps = eval_params.loaded_model.predict_labels(eval_images[b0:b1], batch_size=bs, want_maps=True,
+                                                                       bg_ilm=True, bg_csi=False)
         predict_time = (time.time() - start_predict_time) / (b1 - b0)
         for ind in range(b0, b1):
             eval_image, eval_image_name = eval_images[ind], eval_image_names[ind]
@@ -116,7 +117,7 @@ def evaluate_model(eval_params: EvaluationParameters) -> List[EvaluationOutput]:
             os.makedirs(eval_image_output_dir, exist_ok=True)
             predicted_labels = label_maps[ind - b0:ind - b0 + 1].astype(np.int64)          # (1,H,W)
             categorical_pred = common_utils.labels_to_categorical(predicted_labels, num_classes)
-            boundary_maps = common_utils.convert_predictions_to_maps_semantic(categorical_pred, bg_ilm=True, bg_csi=False)
+            boundary_maps = dev_maps[ind - b0:ind - b0 + 1]   # == convert_predictions_to_maps_semantic(categorical_pred), on device
             dice_classes, dice_macro, dice_micro = _dice_metrics(eval_params.metrics, num_classes, eval_label, categorical_pred)
 
             predicted_labels = np.squeeze(predicted_labels, axis=0)

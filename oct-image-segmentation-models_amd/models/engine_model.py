@@ -327,18 +327,23 @@ class Model:
             out[lo:lo + bs] = probs.cpu().numpy()
         return out
 
-    def predict_labels(self, x_u8: np.ndarray, batch_size: int = 32) -> np.ndarray:
+    def predict_labels(self, x_u8: np.ndarray, batch_size: int = 32, want_maps: bool = False, bg_ilm: bool = True,
+                       bg_csi: bool = False):
         """Raw uint8 images -> uint8 arg-max class maps (n,H,W), computed on the device (1 B/px back instead of
-        4*C B/px)."""
+        4*C B/px).  With ``want_maps`` also the (n, C-1, H, W) uint8 boundary maps of
+        ``convert_predictions_to_maps_semantic``, computed on the device from the class maps."""
         x_u8 = np.ascontiguousarray(x_u8)
         n = x_u8.shape[0]
         eng = self._ensure_engine(min(batch_size, n), False)
         out = np.empty(x_u8.shape[:3], np.uint8)
+        maps = np.empty((n, self.config["num_classes"] - 1) + tuple(x_u8.shape[1:3]), np.uint8) if want_maps else None
         for lo in range(0, n, batch_size):
             xb = torch.from_numpy(x_u8[lo:lo + batch_size]).to(eng.device)
             _, am = eng.forward(xb, training=False, want_probs=False, want_argmax=True)
             out[lo:lo + batch_size] = am.cpu().numpy()
-        return out
+            if want_maps:
+                maps[lo:lo + batch_size] = eng.boundary_maps(am, bg_ilm=bg_ilm, bg_csi=bg_csi).cpu().numpy()
+        return (out, maps) if want_maps else out
 
 
 def load_model(path) -> Model:

@@ -53,7 +53,8 @@ def predict(predict_params: PredictionParams) -> List[PredictionOutput]:
     for b0 in range(lo, hi, bs):
         b1 = min(b0 + bs, hi)
         t0 = time.time()
-        label_maps = predict_params.loaded_model.predict_labels(images[b0:b1], batch_size=bs)
+        label_maps, dev_maps = predict_params.loaded_model.predict_labels(images[b0:b1], batch_size=bs, want_maps=True,
+                                                                          bg_ilm=True, bg_csi=False)
         predict_time = (time.time() - t0) / (b1 - b0)
         for i in range(b0, b1):
             predict_image, image_name, image_output_dir = images[i], dataset.image_names[i], Path(dataset.image_output_dirs[i])
@@ -62,7 +63,7 @@ def predict(predict_params: PredictionParams) -> List[PredictionOutput]:
             start_convert_time = time.time()
             predicted_labels = label_maps[i - b0:i - b0 + 1].astype(np.int64)
             categorical_pred = utils.labels_to_categorical(predicted_labels, num_classes)
-            boundary_maps = utils.convert_predictions_to_maps_semantic(np.array(categorical_pred), bg_ilm=True, bg_csi=False)
+            boundary_maps = dev_maps[i - b0:i - b0 + 1]   # == convert_predictions_to_maps_semantic(categorical_pred), on device
             convert_time = time.time() - start_convert_time
             predicted_labels = np.squeeze(predicted_labels, axis=0)
             categorical_pred = np.squeeze(categorical_pred, axis=0)

@@ -273,3 +273,21 @@ def test_config3_shape_runs_in_fp32():
     cfg = make_cfg(input_channels=1, num_classes=3, image_height=H, image_width=W, pool_layers=5)
     cfg.dtype = 1
     assert _hip.lib().oct_unet_cfg_check(ctypes.byref(cfg)) != 0 and b"f32" in _hip.lib().oct_last_error()
+
+
+def test_device_boundary_maps_match_reference_definition():
+    """arg-max -> boundary maps on the device, bit-exact vs the numpy restatement of
+    common/utils.py:115-168 (including the edge rows, where np.gradient is one-sided and the uint8 cast wraps)."""
+    cfg, eng, _, _ = make(2, 32, 64, 4, 8, 2, training=False)
+    rng = np.random.default_rng(0)
+    _, smooth = on.synth_scans(3, 32, 64, 4, seed=6)
+    cases = [smooth[..., 0], rng.integers(0, 4, (3, 32, 64)).astype(np.uint8)]
+    edge = np.zeros((2, 32, 64), np.uint8); edge[0, 1:, :] = 1; edge[1, :-1, :] = 2; edge[1, -1, :] = 3   # steps at the first / last row
+    cases.append(edge)
+    for lab in cases:
+        cat = np.transpose(np.eye(4, dtype=np.float32)[lab], (0, 3, 1, 2))
+        for kw in (dict(bg_ilm=True, bg_csi=False), dict(bg_ilm=False, bg_csi=True), dict(bg_ilm=True, bg_csi=True)):
+            with np.errstate(invalid="ignore"):
+                ref = on.convert_predictions_to_maps_semantic(cat, **kw)
+            got = eng.boundary_maps(torch.from_numpy(np.ascontiguousarray(lab)).cuda(), **kw).cpu().numpy()
+            assert np.array_equal(got, ref), kw
