@@ -133,52 +133,43 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_k(const PoolBwdArgs A) {
 #pragma unroll
     for (int i = 0; i < C_T; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
     if (valid) {
-        float gpv[C_T], zv[4][C_T], yv[4][C_T];
+        // every tensor element is touched exactly once: z (4 positions), gp, g in, g out
+        float gpv[C_T], zv[4][C_T], gd[4][C_T];
         const float* gpp = A.gp + (((size_t)b * Ho + yo) * Wo + xo) * A.C + c0;
 #pragma unroll
         for (int i = 0; i < C_T; i += 4) { const float4 t = ld4(gpp + i); gpv[i] = t.x; gpv[i + 1] = t.y; gpv[i + 2] = t.z; gpv[i + 3] = t.w; }
+        size_t off[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float* zp = A.z + (((size_t)b * A.H + 2 * yo + (q >> 1)) * A.W + 2 * xo + (q & 1)) * A.C + c0;
+            off[q] = (((size_t)b * A.H + 2 * yo + (q >> 1)) * A.W + 2 * xo + (q & 1)) * A.C + c0;
 #pragma unroll
-            for (int i = 0; i < C_T; i += 4) { const float4 t = ld4(zp + i); zv[q][i] = t.x; zv[q][i + 1] = t.y; zv[q][i + 2] = t.z; zv[q][i + 3] = t.w; }
+            for (int i = 0; i < C_T; i += 4) {
+                const float4 t = ld4(A.z + off[q] + i); zv[q][i] = t.x; zv[q][i + 1] = t.y; zv[q][i + 2] = t.z; zv[q][i + 3] = t.w;
+                const float4 u = ld4(A.g + off[q] + i); gd[q][i] = u.x; gd[q][i + 1] = u.y; gd[q][i + 2] = u.z; gd[q][i + 3] = u.w;
+            }
         }
 #pragma unroll
         for (int i = 0; i < C_T; ++i) {
             const int c = c0 + i;
             const float a = A.bn[BN_A * A.C + c], bb = A.bn[BN_B * A.C + c];
-            int am = 0; float best = -1.f;
+            const float mean = A.bn[BN_MEAN * A.C + c], rstd = A.bn[BN_RSTD * A.C + c];
+            float yv[4]; int am = 0; float best = -1.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                yv[q][i] = fmaxf(fmaf(a, zv[q][i], bb), 0.f);
-                if (yv[q][i] > best) { best = yv[q][i]; am = q; }   // first maximum in row-major window order
+                yv[q] = fmaxf(fmaf(a, zv[q][i], bb), 0.f);
+                if (yv[q] > best) { best = yv[q]; am = q; }   // first maximum in row-major window order
             }
-            // overwrite zv with the routed pool gradient so the store loop below stays branch-free
 #pragma unroll
-            for (int q = 0; q < 4; ++q) zv[q][i] = (q == am ? gpv[i] : 0.f);
-            // keep raw z for xhat in yv's sign: recompute xhat from a: xhat = (z-mean)*rstd, need z again
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const size_t off = (((size_t)b * A.H + 2 * yo + (q >> 1)) * A.W + 2 * xo + (q & 1)) * A.C + c0;
-            float* gq = A.g + off;
-            const float* zp = A.z + off;
-#pragma unroll
-            for (int i = 0; i < C_T; i += 4) {
-                const float4 gd = ld4(gq + i);
-                const float4 zz = ld4(zp + i);
-                const float gdv[4] = {gd.x, gd.y, gd.z, gd.w}, zzv[4] = {zz.x, zz.y, zz.z, zz.w};
-                float o[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int c = c0 + i + k;
-                    const float gt = yv[q][i + k] > 0.f ? gdv[k] + zv[q][i + k] : 0.f;
-                    const float xh = (zzv[k] - A.bn[BN_MEAN * A.C + c]) * A.bn[BN_RSTD * A.C + c];
-                    o[k] = gt; s1[i + k] += gt; s2[i + k] += gt * xh;
-                }
-                st4(gq + i, make_float4(o[0], o[1], o[2], o[3]));
+            for (int q = 0; q < 4; ++q) {
+                const float gt = yv[q] > 0.f ? gd[q][i] + (q == am ? gpv[i] : 0.f) : 0.f;
+                s1[i] += gt; s2[i] += gt * ((zv[q][i] - mean) * rstd);
+                gd[q][i] = gt;
             }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < C_T; i += 4) st4(A.g + off[q] + i, make_float4(gd[q][i], gd[q][i + 1], gd[q][i + 2], gd[q][i + 3]));
     }
     float* out = A.part + ((size_t)b * A.tiles + tile) * (2 * A.C);
     block_reduce_store<C_T>(s1, red, out + c0, C_T);

@@ -641,7 +641,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
                 PoolBwdArgs pb{};
                 pb.gp = h->gpooled[l.level - 1]; pb.z = p.z; pb.bn = p.bn; pb.g = p.g; pb.part = h->stat_part;
                 pb.H = p.H; pb.W = p.W; pb.C = p.cout; pb.tiles_x = cdiv(p.W / 2, kTileX); pb.tiles = tiles_of(p.H / 2, p.W / 2);
-                const int c_t = std::min(chunk_of(p.cout), 8);
+                const int c_t = 4;
                 dim3 grid(pb.tiles, p.cout / c_t, B);
                 ProfScope ps(s, c_t == 8 ? "pool_bwd_k<8>" : "pool_bwd_k<4>", p.name, 0, (double)B * p.H * p.W * p.cout * 4 * 3.25);
                 if (c_t == 8) pool_bwd_k<8><<<grid, kBlock, 0, s>>>(pb); else pool_bwd_k<4><<<grid, kBlock, 0, s>>>(pb);
