@@ -93,10 +93,13 @@ def main():
     from oct_image_segmentation_models_amd.common.synthetic import make_scans
     from oct_image_segmentation_models_amd.engine import UNetEngine
 
-    rank, local_rank, world = parallel.init("nccl")
+    # OCT_BENCH_REHEARSAL=1: multi-process rehearsal on a ONE-GPU box (all ranks share cuda:0, gloo collective);
+    # never used by the driver -- real runs are one rank per GPU over RCCL
+    rehearsal = os.environ.get("OCT_BENCH_REHEARSAL") == "1"
+    rank, local_rank, world = parallel.init("gloo" if rehearsal else "nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     B, H, W, C = args.batch, args.height, args.width, args.classes
 
@@ -211,6 +214,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(H, W, C)
     if rank == 0:
+        if rehearsal:
+            out["data"] = "synthetic (REHEARSAL: ranks share one GPU, gloo collective -- not a measurement)"
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -5,108 +5,13 @@
 //     per-block partials of  sum(g')  and  sum(g' * xhat)  (the two BN-backward reductions = dbeta, dgamma);
 //   * bn_bwd_finalize turns the partials into c1 = sum(g')/N, c2 = sum(g' xhat)/N and dgamma/dbeta;
 //   * bn_bwd_apply rewrites g' in place into dz = gamma*rstd*(g' - c1 - xhat*c2);
-//   * conv_bwd_w reduces dW = sum x (x) dz, conv_bwd_data scatters dz back to the block's input(s).
+//   * the dW kernels (kernels_dw.hpp) reduce dW = sum x (x) dz; backward-data runs through the implicit-GEMM /
+//     thin-layer conv kernels (kernels_igemm.hpp, kernels_thin.hpp) with transposed / effective weights.
 #pragma once
 #include "common.hpp"
 #include "kernels_fwd.hpp"
 
 namespace oct {
-
-// ---- epilogue shared by every producer of a BN block's output gradient -----------------------------------
-// g[CI_T] = dL/dy at one pixel for channels [c0, c0+CI_T) -> masked by the block's ReLU, statistics emitted.
-template <int CI_T, bool DROP>
-__device__ inline void mask_and_stats(float (&g)[CI_T], bool valid, const float* __restrict__ zin_px,
-                                      const float* __restrict__ bn, int C, int c0, uint32_t elem0,
-                                      const DropCfg& drop, float* red, float* part_out) {
-    float s1[CI_T], s2[CI_T];
-#pragma unroll
-    for (int i = 0; i < CI_T; i += 4) {
-        const float4 zv = valid ? ld4(zin_px + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = c0 + i + k;
-            const float yv = fmaf(bn[BN_A * C + c], zz[k], bn[BN_B * C + c]);
-            float gv = g[i + k];
-            if constexpr (DROP) gv *= drop_mul(drop, elem0 + i + k);
-            gv = (valid && yv > 0.f) ? gv : 0.f;
-            const float xh = (zz[k] - bn[BN_MEAN * C + c]) * bn[BN_RSTD * C + c];
-            g[i + k] = gv; s1[i + k] = gv; s2[i + k] = gv * xh;
-        }
-    }
-    block_reduce_store<CI_T>(s1, red, part_out + c0, CI_T);
-    block_reduce_store<CI_T>(s2, red, part_out + C + c0, CI_T);
-}
-
-// ---- conv backward-data -------------------------------------------------------------------------------------
-struct ConvBwdDataArgs {
-    const float* dz;  // (B,H,W,Cout)
-    const float* w;   // (KH,KW,Cin_total,Cout)
-    int Cin_total, Cout, ci_off;
-    float* g;         // (B,Hg,Wg,Cg) gradient wrt this group of input channels
-    int Cg;
-    int H, W;         // dz dims
-    int Hg, Wg, tiles_x, tiles;
-    const float* zin; // producer's raw output (B,Hg,Wg,Cg)   [EPI]
-    const float* bnin;
-    float* part;      // [B*tiles][2*Cg]
-    int accumulate;   // RAW epilogue: g += (second writer of a skip gradient)
-    DropCfg drop;
-};
-
-enum { E_RAW = 0, E_MASK = 1, E_MASK_DROP = 2 };
-
-// One thread = one pixel of the INPUT tensor x CI_T input channels.  grid (tiles, Cg/CI_T, B).
-// UP: the conv consumed a nearest-upsampled tensor, so the 2x2 window sum (UpSampling2D grad) is fused here.
-template <int KH, int CI_T, bool UP, int EPI>
-__global__ __launch_bounds__(kBlock) void conv_bwd_data_k(const ConvBwdDataArgs A) {
-    constexpr int KW = KH, PT = (KH - 1) / 2;
-    __shared__ float red[256];
-    const int tx = threadIdx.x & (kTileX - 1), ty = threadIdx.x / kTileX;
-    const int tile = blockIdx.x;
-    const int x = (tile % A.tiles_x) * kTileX + tx, y = (tile / A.tiles_x) * kTileY + ty;
-    const int b = blockIdx.z, c0 = blockIdx.y * CI_T;
-    const bool valid = x < A.Wg && y < A.Hg;
-    float acc[CI_T];
-#pragma unroll
-    for (int i = 0; i < CI_T; ++i) acc[i] = 0.f;
-
-    constexpr int NS = UP ? 2 : 1;
-    for (int dy = 0; dy < NS; ++dy)
-        for (int dx = 0; dx < NS; ++dx) {
-            const int Y = UP ? 2 * y + dy : y, X = UP ? 2 * x + dx : x;
-            for (int ky = 0; ky < KH; ++ky)
-                for (int kx = 0; kx < KW; ++kx) {
-                    const int oy = Y - ky + PT, ox = X - kx + PT;
-                    const bool inb = valid && oy >= 0 && oy < A.H && ox >= 0 && ox < A.W;
-                    const float* dp = A.dz + (inb ? (((size_t)b * A.H + oy) * A.W + ox) * A.Cout : 0);
-                    const float* wk = A.w + ((size_t)(ky * KW + kx) * A.Cin_total + A.ci_off + c0) * A.Cout;
-                    for (int co = 0; co < A.Cout; co += 4) {
-                        const float4 d = inb ? ld4(dp + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int i = 0; i < CI_T; ++i) {
-                            const float* wr = wk + (size_t)i * A.Cout + co;
-                            acc[i] = fmaf(d.x, wr[0], fmaf(d.y, wr[1], fmaf(d.z, wr[2], fmaf(d.w, wr[3], acc[i]))));
-                        }
-                    }
-                }
-        }
-    const size_t pix = valid ? ((size_t)b * A.Hg + y) * A.Wg + x : 0;
-    if constexpr (EPI != E_RAW) {
-        mask_and_stats<CI_T, EPI == E_MASK_DROP>(acc, valid, A.zin + pix * A.Cg + c0, A.bnin, A.Cg, c0,
-                                                 (uint32_t)(pix * A.Cg + c0), A.drop, red,
-                                                 A.part + ((size_t)b * A.tiles + tile) * (2 * A.Cg));
-    }
-    if (valid) {
-        float* gp = A.g + pix * A.Cg + c0;
-#pragma unroll
-        for (int i = 0; i < CI_T; i += 4) {
-            float4 o = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
-            if (EPI == E_RAW && A.accumulate) { const float4 p = ld4(gp + i); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-            st4(gp + i, o);
-        }
-    }
-}
 
 // ---- max-pool backward + skip-gradient merge + ReLU mask + BN-backward statistics ---------------------------
 // The encoder block's output y feeds (i) the pool and (ii) the decoder concat.  gskip already holds the

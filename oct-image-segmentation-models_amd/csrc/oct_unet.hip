@@ -378,14 +378,10 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
         g.part = a.part; g.drop = a.drop;
         rc = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows)
                              : launch_igemm<3, A_NORMAL, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows);
-    } else
-    switch (l.src) {
-        case SRC_INPUT: rc = x_is_u8 ? launch_conv_fwd_co<3, F_U8>(a, B, s, l.name, fl, by) : launch_conv_fwd_co<3, 0>(a, B, s, l.name, fl, by); break;
-        case SRC_POOL: rc = launch_conv_fwd_co<3, 0>(a, B, s, l.name, fl, by); break;
-        case SRC_PREV: rc = launch_conv_fwd_co<3, F_AFF>(a, B, s, l.name, fl, by); break;
-        case SRC_CONCAT: rc = launch_conv_fwd_co<3, F_AFF | F_TWO>(a, B, s, l.name, fl, by); break;
-        case SRC_UP: rc = drop ? launch_conv_fwd_co<2, F_AFF | F_UP | F_DROP>(a, B, s, l.name, fl, by) : launch_conv_fwd_co<2, F_AFF | F_UP>(a, B, s, l.name, fl, by); break;
-        default: return fail(-3, "conv_forward: bad src");
+    } else if (l.src == SRC_INPUT) {   // first layer: 1 (or odd) input channels, uint8 /255 table on load -> VALU direct conv
+        rc = x_is_u8 ? launch_conv_fwd_co<3, F_U8>(a, B, s, l.name, fl, by) : launch_conv_fwd_co<3, 0>(a, B, s, l.name, fl, by);
+    } else {
+        return fail(-3, "conv_forward: channel count not a multiple of 4");
     }
     if (rc) return rc;
     if (l.has_bn && training) {
