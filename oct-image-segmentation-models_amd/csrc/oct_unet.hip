@@ -188,6 +188,7 @@ struct oct_unet {
     const void* last_x = nullptr; int last_u8 = 0;   // input of the last forward (first layer's dW re-reads it)
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     Profiler prof;
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // dW runs beside dX (backward)
 };
 
 namespace {
@@ -603,7 +604,10 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         // g buffer of block li is complete (+ partials in stat_part) -> dz in place
         rc = bn_backward(h, li, pending_nblk, B, s);
         if (rc) return rc;
-        rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s);
+        // dW only reads dz / saved activations and writes its own slabs: it runs on the side stream, beside dX
+        HIP_OK(hipEventRecord(h->ev_fork, s));
+        HIP_OK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, h->side);
         if (rc) return rc;
         if (l.src == SRC_INPUT) break;
         // backward-data through the MFMA implicit-GEMM kernel: dz (plain) x transposed / effective weights
@@ -667,6 +671,8 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         }
         if (rc) return rc;
     }
+    HIP_OK(hipEventRecord(h->ev_join, h->side));      // all dW slabs written before the single reduce launch
+    HIP_OK(hipStreamWaitEvent(s, h->ev_join, 0));
     return flush_reduce(h, s);
 }
 
@@ -747,6 +753,13 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_u8_lut), lut, sizeof lut);
     if (e != hipSuccess) { delete h; return fail(-5, std::string("hipMemcpyToSymbol: ") + hipGetErrorString(e)); }
+    if (c->training) {
+        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+            delete h; return fail(-5, "could not create the side stream / events");
+        }
+    }
     *out = h;
     return 0;
 }
@@ -755,6 +768,9 @@ void oct_unet_destroy(oct_unet* h) {
     if (!h) return;
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
 }
 

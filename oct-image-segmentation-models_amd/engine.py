@@ -104,7 +104,10 @@ class UNetEngine:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            _hip.lib().oct_unet_destroy(h)
+            try:
+                _hip.lib().oct_unet_destroy(h)
+            except Exception:   # interpreter teardown: module globals may already be gone
+                pass
             self._h = None
 
     # ---- plumbing --------------------------------------------------------------------------------
