@@ -191,11 +191,9 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            key = name.replace("conv_igemm_k<", "conv_igemm_k<").split(">")[0]
-            for k, v in pmc.items():
-                if k.replace(" ", "").startswith(key.replace(" ", "")):
-                    traffic = round(v["hbm_bytes_per_launch"], 0)
-                    break
+            v = pmc.get(name)    # the profiler tags are the exact instantiation names rocprofv3 reports
+            if v is not None:
+                traffic = round(v["hbm_bytes_per_launch"], 0)
         except (OSError, KeyError, ValueError):
             traffic = None
         roof.update({"traffic": traffic, "kernel": name, "avg_launch_us": round(avg_us, 2),

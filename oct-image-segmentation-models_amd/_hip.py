@@ -89,6 +89,9 @@ def lib() -> C.CDLL:
             raise OctError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(csrc/build.sh).  There is no fallback implementation.")
+        # torch ships its own HIP runtime (libamdhip64): it must be in the process BEFORE this library is loaded, so
+        # that both resolve to the same runtime instance (otherwise: "no ROCm-capable device is detected")
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(l, name)  # AttributeError if the ABI is incomplete

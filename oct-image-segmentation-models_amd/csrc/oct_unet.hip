@@ -188,7 +188,6 @@ struct oct_unet {
     const void* last_x = nullptr; int last_u8 = 0;   // input of the last forward (first layer's dW re-reads it)
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     Profiler prof;
-    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // dW runs beside dX (backward)
 };
 
 namespace {
@@ -285,7 +284,7 @@ template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN>
 int launch_igemm_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
     a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH);
     dim3 grid(a.tiles, cdiv(a.Mout, MB), B), block(kBlock);
-    char nm[48]; snprintf(nm, sizeof nm, "conv_igemm_k<%d,%d,%d,%d,%d,%d>", SHAPE, KH, AMODE, EPI, TH, MB);
+    char nm[48]; snprintf(nm, sizeof nm, "conv_igemm_k<%d,%d,%d,%d,%d,%d,%d>", SHAPE, KH, AMODE, EPI, TH, MB, WN);
     ProfScope ps(s, nm, layer, flops, bytes);
     conv_igemm_k<SHAPE, KH, AMODE, EPI, TH, MB, WN><<<grid, block, 0, s>>>(a);
     HIP_OK(hipGetLastError());
@@ -299,7 +298,7 @@ int launch_igemm_p(IgemmArgs a, int B, hipStream_t s, const char* layer, double 
     a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH); a.total_tiles = B * a.tiles;
     const int nblk = std::min(a.total_tiles, 1280);    // ~5 resident blocks per CU
     dim3 grid(nblk, cdiv(a.Mout, MB), 1), block(kBlock);
-    char nm[48]; snprintf(nm, sizeof nm, "conv_igemm_p_k<%d,%d,%d,%d,%d,%d,%d>", SHAPE, KH, AMODE, EPI, TH, MB, KCP);
+    char nm[48]; snprintf(nm, sizeof nm, "conv_igemm_p_k<%d,%d,%d,%d,%d,%d,%d,%d>", SHAPE, KH, AMODE, EPI, TH, MB, WN, KCP);
     ProfScope ps(s, nm, layer, flops, bytes);
     conv_igemm_p_k<SHAPE, KH, AMODE, EPI, TH, MB, WN, KCP><<<grid, block, 0, s>>>(a);
     HIP_OK(hipGetLastError());
@@ -547,7 +546,9 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const fl
         rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by);   // 1-channel (or odd-channel) first layer
     } else {
         dim3 grid(p.npb, cdiv(l.cin, p.cic), cdiv(l.cout, p.coc)), block(kBlock);
-        char nm[48]; snprintf(nm, sizeof nm, "conv_dw%d_k<%d,%d,%d>", p.kind, l.kh, p.cic, (int)up);
+        char nm[48];
+        if (p.kind == 16) snprintf(nm, sizeof nm, "conv_dw16_k<%d,%d,%s>", l.kh, p.cic, up ? "true" : "false");
+        else snprintf(nm, sizeof nm, "conv_dw32_k<%d,%d,%s,%d>", l.kh, p.cic, up ? "true" : "false", p.th);
         ProfScope ps(s, nm, l.name, fl, by);
         if (p.kind == 16) {
             if (up) { if (p.cic == 16) conv_dw16_k<2, 16, true><<<grid, block, 0, s>>>(a); else conv_dw16_k<2, 8, true><<<grid, block, 0, s>>>(a); }
@@ -604,10 +605,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         // g buffer of block li is complete (+ partials in stat_part) -> dz in place
         rc = bn_backward(h, li, pending_nblk, B, s);
         if (rc) return rc;
-        // dW only reads dz / saved activations and writes its own slabs: it runs on the side stream, beside dX
-        HIP_OK(hipEventRecord(h->ev_fork, s));
-        HIP_OK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, h->side);
+        rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s);
         if (rc) return rc;
         if (l.src == SRC_INPUT) break;
         // backward-data through the MFMA implicit-GEMM kernel: dz (plain) x transposed / effective weights
@@ -671,8 +669,6 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         }
         if (rc) return rc;
     }
-    HIP_OK(hipEventRecord(h->ev_join, h->side));      // all dW slabs written before the single reduce launch
-    HIP_OK(hipStreamWaitEvent(s, h->ev_join, 0));
     return flush_reduce(h, s);
 }
 
@@ -753,13 +749,6 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_u8_lut), lut, sizeof lut);
     if (e != hipSuccess) { delete h; return fail(-5, std::string("hipMemcpyToSymbol: ") + hipGetErrorString(e)); }
-    if (c->training) {
-        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
-            delete h; return fail(-5, "could not create the side stream / events");
-        }
-    }
     *out = h;
     return 0;
 }
@@ -768,9 +757,6 @@ void oct_unet_destroy(oct_unet* h) {
     if (!h) return;
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
-    if (h->side) (void)hipStreamDestroy(h->side);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
 }
 
