@@ -1,5 +1,5 @@
 """Batch generator with the reference's input contract
-(oct_image_segmentation_models/common/data_generator.py:10-416), re-stated for augmentation mode "none":
+(oct_image_segmentation_models/common/data_generator.py:10-416), re-stated with all three augmentation modes:
 
 * ``X = float32(images / 255)`` of shape (B,H,W,C) -- the reference computes ``u8/255*255/255``
   (data_generator.py:76,239 + models/unet.py:89), within one ulp of this;
@@ -8,7 +8,13 @@
   ``index`` argument and must be consumed sequentially; ``on_epoch_end`` composes a fresh permutation onto
   the previous one (``sample_shuffle = sample_shuffle[s]``), seeded from the OS unless a seed is given.
 
-Batches are assembled with one fancy-indexing gather instead of the reference's per-sample Python loop
+Augmentation (reference :140-283): ``aug_fn_args`` is a list of ``(function, arguments)`` pairs
+from ``common.augmentation``; mode "all" repeats every image once per augmentation (``total_samples = N * n_augs``),
+mode "one" draws one augmentation per sample with ``aug_probs``; ``aug_fly=False`` pre-computes the augmented set.
+The pre-computed set is kept in float32 (the reference stores the [0,1] floats into a uint8 array, which zeroes
+every image -- a defect not reproduced here).  Augmented batches take the float32 input path of the engine.
+
+Without augmentation, batches are assembled with one fancy-indexing gather instead of the reference's per-sample Python loop
 (SURVEY 3.1 hot loop ii).  ``next_batch_u8`` is the engine's fast path: uint8 images + uint8 sparse labels,
 so the /255 happens on the GPU while the first conv loads the image."""
 from __future__ import annotations
@@ -27,9 +33,6 @@ class BatchGenerator:
         if aug_mode not in ("none", "one", "all"):
             log.error(f"Unrecognized augmentation mode: {aug_mode}. Allowed values: 'none', 'one', 'all'. Exiting...")
             exit(1)
-        if aug_mode != "none":
-            raise NotImplementedError("augmentation modes 'one'/'all' are outside the accelerated path "
-                                      "(SURVEY 8f row f4); use aug_mode='none'")
         self.images_u8 = np.ascontiguousarray(images)
         self.labels = labels
         self.batch_size = int(batch_size)
@@ -37,8 +40,12 @@ class BatchGenerator:
         self.preprocess_input_fn = preprocess_input_fn
         self.total_full_images = self.images_u8.shape[0]
         self.total_raw_samples = self.total_full_images
-        self.total_samples = self.total_raw_samples
-        self.total_augs = 0
+        self.total_augs = 0 if aug_mode == "none" else len(aug_fn_args)
+        self.total_samples = self.total_raw_samples * self.total_augs if aug_mode == "all" else self.total_raw_samples
+        if aug_mode != "none" and self.total_augs == 0:
+            raise ValueError("aug_mode '%s' needs at least one augmentation function" % aug_mode)
+        if aug_mode == "one" and (len(aug_probs) != self.total_augs or abs(sum(aug_probs) - 1.0) > 1e-6):
+            raise ValueError("aug_probs must hold one probability per augmentation and sum to 1")
         self.image_height, self.image_width, self.num_channels = self.images_u8.shape[1:4]
         self.labels_shape = self.labels.shape
         self.batch_labels_shape = (self.batch_size,) + tuple(self.labels_shape[1:])
@@ -47,7 +54,40 @@ class BatchGenerator:
         self._rng = np.random.default_rng(seed)  # seed=None: OS entropy, as the reference's np.random.seed()
         self._sparse_cache = None
         self.batch_counter = self.full_counter = self.aug_counter = 0
+        self.images = None if aug_mode == "none" else self.images_u8.astype(np.float32) / np.float32(255.0)
+        if self.aug_fly is False and self.aug_mode != "none":
+            self.aug_images, self.aug_labels = self.setup_augnofly_data()
         self.handle_epoch_end()
+
+    def setup_augnofly_data(self):
+        """Pre-computed augmentations: (N, n_augs, H, W, C) float32 images and (N, n_augs, ...) labels."""
+        aug_images = np.zeros((self.total_full_images, self.total_augs) + self.images.shape[1:], dtype=np.float32)
+        aug_labels = np.zeros((self.total_full_images, self.total_augs) + tuple(self.labels_shape[1:]), dtype=self.labels.dtype)
+        for i in range(self.total_full_images):
+            for j, (aug_fn, aug_arg) in enumerate(self.aug_fn_args):
+                aug_images[i, j], aug_labels[i, j] = aug_fn(self.images[i], self.labels[i], aug_arg)
+        return aug_images, aug_labels
+
+    def _next_augmented(self):
+        """One (image in [0,1], label) sample with the reference's counter semantics (get_aug_fly / get_aug_nofly)."""
+        ind = self.sample_shuffle[self.full_counter]
+        if self.aug_mode == "all":
+            j = self.aug_counter
+            self.aug_counter += 1
+            if self.aug_counter == self.total_augs:
+                self.aug_counter = 0
+                self.full_counter += 1
+        else:  # "one"
+            j = int(self._rng.choice(np.arange(self.total_augs), p=self.aug_probs))
+            self.full_counter += 1
+        if self.aug_fly:
+            aug_fn, aug_arg = self.aug_fn_args[j]
+            img, lab = aug_fn(self.images[ind], self.labels[ind], aug_arg)
+        else:
+            img, lab = self.aug_images[ind, j], self.aug_labels[ind, j]
+        if self.full_counter == self.total_full_images:
+            self.full_counter = 0
+        return img, lab
 
     def _next_indices(self) -> np.ndarray:
         idx = np.empty(self.batch_size, dtype=np.int64)
@@ -62,6 +102,15 @@ class BatchGenerator:
         return idx
 
     def get_batch_list(self):
+        if self.aug_mode != "none":
+            batch_images = np.zeros((self.batch_size,) + self.images.shape[1:], dtype="float32")
+            batch_labels = np.zeros(self.batch_labels_shape)
+            for k in range(self.batch_size):
+                batch_images[k], batch_labels[k] = self._next_augmented()
+            self.batch_counter += 1
+            if self.batch_counter == self.num_batches:
+                self.batch_counter = 0
+            return [batch_images, batch_labels]
         idx = self._next_indices()
         batch_images = (self.images_u8[idx].astype(np.float32)) / np.float32(255.0)
         batch_labels = np.asarray(self.labels[idx], dtype=np.float64)  # the reference's label buffer is float64
@@ -93,11 +142,10 @@ class BatchGenerator:
 class DataGenerator:
     """``keras.utils.Sequence`` duck type: ``__len__``, ``__getitem__``, ``on_epoch_end``."""
 
-    oct_fast_path = True
-
     def __init__(self, images: np.ndarray, labels: np.ndarray, batch_size: int, aug_fn_args: List[Tuple],
                  aug_mode: str, aug_probs: Tuple, aug_fly: bool, preprocess_input_fn: Callable,
                  seed: Optional[int] = None):
+        self.oct_fast_path = aug_mode == "none"   # uint8 fast path only without augmentation
         self.batch_gen = BatchGenerator(images=images, labels=labels, batch_size=batch_size, aug_fn_args=aug_fn_args,
                                         aug_mode=aug_mode, aug_probs=aug_probs, aug_fly=aug_fly,
                                         preprocess_input_fn=preprocess_input_fn, seed=seed)

@@ -156,10 +156,13 @@ def train_model(training_params: TrainingParams, mlflow_params=None):
                                   training_dataset_md5, c_weight, timestamp, training_params, optimizer)
 
     seed = training_params.seed
-    train_gen = data_gen.DataGenerator(train_images, train_labels, batch_size, [], training_params.aug_mode,
+    train_gen = data_gen.DataGenerator(train_images, train_labels, batch_size, training_params.aug_fn_args, training_params.aug_mode,
                                        training_params.aug_probs, training_params.aug_fly,
                                        model_container.get_preprocess_input_fn(), seed=seed)
-    val_gen = data_gen.DataGenerator(val_images, val_labels, batch_size, [], aug_val_mode, (), False,
+    val_gen = data_gen.DataGenerator(val_images, val_labels, batch_size,
+                                     training_params.aug_fn_args if aug_val_mode != "none" else [], aug_val_mode,
+                                     training_params.aug_probs if aug_val_mode != "none" else (),
+                                     training_params.aug_fly if aug_val_mode != "none" else False,
                                      model_container.get_preprocess_input_fn(),
                                      seed=None if seed is None else seed + 1)
 

@@ -7,6 +7,7 @@ from pathlib import Path
 from typing import List, Tuple, Union
 
 from ..common import AUG_MODES
+from ..common import augmentation as aug
 
 
 class TrainingParams:
@@ -39,10 +40,13 @@ class TrainingParams:
             log.error(f"Augmentation mode: '{aug_mode}' is not supported.")
             exit(1)
         self.aug_mode = aug_mode
-        if augmentations and aug_mode != "none":
-            log.error("Augmentation functions are outside the accelerated path (SURVEY 8f row f4).")
-            exit(1)
         self.aug_fn_args = []
+        for augmentation in augmentations:
+            aug_fn = aug.augmentation_map.get(augmentation["name"])
+            if aug_fn is None:
+                log.error(f"Augmentation: '{augmentation['name']}' is not supported.")
+                exit(1)
+            self.aug_fn_args.append((aug_fn, augmentation.get("arguments", {})))
         self.augmentations = augmentations
         self.aug_probs = aug_probs
         self.aug_fly = aug_fly

@@ -87,8 +87,42 @@ def test_data_generator_contract():
     g2 = DataGenerator(images[:5], labels[:5], 4, [], "none", (), False, None, seed=1)
     idx = [g2.batch_gen._next_indices() for _ in range(3)]
     assert np.array_equal(np.concatenate(idx)[:10], np.tile(g2.batch_gen.sample_shuffle, 3)[:10])
-    with pytest.raises(NotImplementedError):
-        DataGenerator(images, labels, 4, [], "one", (), False, None)
+    with pytest.raises(ValueError):
+        DataGenerator(images, labels, 4, [], "one", (), False, None)   # an augmentation mode needs augmentations
+
+
+def test_data_generator_augmentation_modes():
+    """'all' / 'one' modes, fly / pre-computed, flip exact, noise within its documented range."""
+    from oct_image_segmentation_models_amd.common import augmentation as aug
+    from oct_image_segmentation_models_amd.common.data_generator import DataGenerator
+    rng = np.random.default_rng(2)
+    images = rng.integers(0, 256, (6, 4, 8, 1)).astype(np.uint8)
+    labels = rng.integers(0, 3, (6, 4, 8, 1)).astype(np.uint8)
+    fns = [(aug.augmentation_map["no_augmentation"], {}), (aug.augmentation_map["flip"], {"flip_type": "left-right"}),
+           (aug.augmentation_map["flip"], {"flip_type": "up-down"})]
+    for fly in (True, False):
+        g = DataGenerator(images, labels, 3, fns, "all", (), fly, lambda x: x / 255.0, seed=1)
+        assert g.get_total_samples() == 18 and len(g) == 6 and not g.oct_fast_path
+        order = g.batch_gen.sample_shuffle.copy()
+        X, y = g[0]          # first image with each of the three augmentations, in registry order
+        f = images[order[0]].astype(np.float32) / np.float32(255)
+        assert X.dtype == np.float32 and np.array_equal(X[0], f) and np.array_equal(X[1], f[:, ::-1]) and np.array_equal(X[2], f[::-1])
+        assert np.array_equal(y[1], labels[order[0]][:, ::-1]) and np.array_equal(y[2], labels[order[0]][::-1])
+        X2, _ = g[1]
+        assert np.array_equal(X2[0], images[order[1]].astype(np.float32) / np.float32(255))
+    g = DataGenerator(images, labels, 6, fns, "one", (0.0, 1.0, 0.0), True, None, seed=3)
+    assert g.get_total_samples() == 6 and len(g) == 1
+    order = g.batch_gen.sample_shuffle.copy()
+    X, y = g[0]
+    assert all(np.array_equal(X[k], (images[order[k]].astype(np.float32) / np.float32(255))[:, ::-1]) for k in range(6))
+    with pytest.raises(ValueError):
+        DataGenerator(images, labels, 3, fns, "one", (0.5, 0.5), True, None)
+    aug.seed(0)
+    img = images[0].astype(np.float64) / 255.0
+    for mode in ("gaussian", "speckle", "s&p"):
+        out, lab = aug.add_noise_aug(img, labels[0], {"mode": mode, "mean": 0.0, "variance": 0.01})
+        assert out.shape == img.shape and out.min() >= 0 and out.max() <= 1 and np.shares_memory(lab, labels) and not np.array_equal(out, img)
+    assert aug.flip_aug(None, None, {"flip_type": "up-down"}, True) == "flip aug: up-down"
 
 
 def test_postprocess_helpers_match_oracle():
