@@ -166,3 +166,22 @@ def test_synth_scans_all_classes():
     im, lab = on.synth_scans(3, 64, 128, 4, seed=1)
     assert im.shape == (3, 64, 128, 1) and im.dtype == np.uint8 and lab.dtype == np.uint8
     assert len(np.unique(lab)) == 4
+
+
+def test_oracle_reproduces_committed_golden():
+    """The committed fixture (tests/golden/unet_golden.npz, made by make_unet_golden.py) pins the oracle."""
+    import os
+    from tests.helpers import dropout_keep_mask
+    from tests.golden.make_unet_golden import CFG, B, H, W
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_golden.npz"))
+    cfg = on.UNetConfig(**CFG)
+    params = on.unflatten_params(cfg, G["params_flat"].astype(np.float64))
+    state = on.unflatten_state(cfg, G["state_flat"].astype(np.float64))
+    x = on.preprocess_u8(G["images"], np.float64)
+    mask = dropout_keep_mask(int(G["dropout_seed"]), int(G["dropout_step"]), (B, H >> 2, W >> 2, 16)).astype(np.float64)
+    pi, _ = on.forward(cfg, params, state, x, training=False)
+    pt, cache = on.forward(cfg, params, state, x, training=True, dropout_mask=mask)
+    assert np.abs(pi - G["probs_infer"]).max() < 1e-13 and np.abs(pt - G["probs_train"]).max() < 1e-13
+    _, grads = on.backward(cfg, params, cache, G["labels"], macro=True)
+    assert np.abs(on.flatten_grads(grads) - G["grads_macro"]).max() < 1e-13
+    assert np.abs(on.flatten_state(on.updated_moving_stats(cfg, state, cache)) - G["state_after"]).max() < 1e-13

@@ -28,7 +28,9 @@ def report(case, macro=True):
         yb = p64[li]["gamma"] * cache[li]["xhat"] + p64[li]["beta"]
         if e.max() / sc > 1e-3:
             bad = np.argwhere(e > 1e-3 * sc)
-            print("     pre-activation (gamma*xhat+beta) at outliers:", [f"{yb[tuple(i)]:.2e}" for i in bad[:8]])
+            print("     pre-activation (gamma*xhat+beta) at outliers:", [f"{yb[tuple(i)]:.2e}" for i in bad[:6]],
+                  " rel L2 err", f"{np.linalg.norm(dz - r) / np.linalg.norm(r):.2e}", " frac>1e-3:", f"{(e > 1e-3 * sc).mean():.2e}",
+                  " min|yb|", f"{np.abs(yb).min():.1e}")
         print(f"L{li:2d} {plan[li].name:12s} dz max|r|={sc:.3e} maxerr/sc={e.max()/sc:.2e} med={np.median(e)/sc:.1e} "
               f"n(>1e-3)={int((e > 1e-3*sc).sum())} at {idx} y_ref={y[idx]:.3e} z_ref={cache[li]['z'][idx]:.4f} dz={dz[idx]:.4e} ref={r[idx]:.4e}")
     g = eng.grads.cpu().numpy()
@@ -43,4 +45,8 @@ def report(case, macro=True):
         print(f"  grad {L_['name']:12s} " + " ".join(out))
 
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "full":
+        report((2, 256, 512, 3, 8, 4, 2, 1))
+        sys.exit(0)
     report((2, 32, 64, 3, 8, 2, 2, 1))
