@@ -329,6 +329,10 @@ def test_full_size_parity_with_real_kernel_selection():
     cfg, eng, p64, s64 = make(B, H, W, C, 8, 4, training=True)
     images, labels = data(B, H, W, C, seed=21)
     x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+    # inference first (training forwards update the moving statistics)
+    probs_i, am = eng.forward(x, training=False, want_argmax=True)
+    ref_i, _ = on.forward(cfg, p64, s64, on.preprocess_u8(images, np.float64), training=False)
+    assert np.abs(probs_i.cpu().numpy() - ref_i).max() < PROB_TOL
     eng.set_dropout_step(2)
     mask = eng.dropout_mask(B).cpu().numpy().astype(np.float64)
     probs, _ = eng.forward(x, training=True, labels=lab)
@@ -366,6 +370,3 @@ def test_full_size_parity_with_real_kernel_selection():
     fd = (vals[0] - vals[1]) / (2 * eps)
     gv = float((gt * v).sum())
     assert abs(fd - gv) < 0.03 * abs(gv), (fd, gv)
-    probs_i, am = eng.forward(x, training=False, want_argmax=True)
-    ref_i, _ = on.forward(cfg, p64, s64, on.preprocess_u8(images, np.float64), training=False)
-    assert np.abs(probs_i.cpu().numpy() - ref_i).max() < PROB_TOL
