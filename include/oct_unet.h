@@ -50,7 +50,8 @@ typedef struct oct_unet_cfg {
     int conv_layers;      /* default 2                            (unet.py:71)          */
     int enc_k;            /* 3  (enc_kernel (3,3))                (unet.py:72)          */
     int dec_k;            /* 2  (dec_kernel (2,2))                (unet.py:73)          */
-    int dtype;            /* 0 = f32 storage + f32 arithmetic (only mode implemented)   */
+    int dtype;            /* 0 = f32; 1 = bf16 STORAGE of activations / activation gradients,   */
+                          /*     f32 arithmetic, f32 BN statistics, f32 parameters + gradients  */
     int training;         /* 1: workspace also holds saved activations + gradients      */
     float bn_eps;         /* 1e-3  keras BatchNormalization default                     */
     float bn_momentum;    /* 0.99                                                       */
@@ -143,7 +144,9 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
 int oct_set_option(const char* name, int value);
 
 /* ---- introspection for tests: device pointer of a layer's saved pre-BN output / gradient ---- */
-const float* oct_unet_debug_activation(oct_unet* h, int layer, int which /*0=z,1=g*/);
+/* which: 0 = z, 1 = g (f32 or bf16 per cfg.dtype; max_batch x out_h x out_w x cout);
+ *        2 = the layer's BN record, f32 [6][cout]: a, b (y = relu(a*z + b)), batch/moving mean, rstd, c1, c2 */
+const void* oct_unet_debug_activation(oct_unet* h, int layer, int which);
 
 const char* oct_last_error(void);
 const char* oct_version(void);

@@ -92,4 +92,31 @@ __host__ __device__ inline int chan_of_lane(int lane) {
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ inline void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 
+// ---- activation storage type: float (dtype 0) or bfloat16 (dtype 1: bf16 STORAGE of activations and activation
+// gradients; all arithmetic, BN statistics, parameters and parameter gradients stay fp32) ----
+typedef unsigned short bf16_t;
+__device__ inline float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ inline bf16_t f2bf(float f) {   // round to nearest even (finite inputs; the network never stores NaN/Inf)
+    const uint32_t u = __float_as_uint(f);
+    return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+template <typename AT> __device__ inline float4 lda4(const AT* p);
+template <> __device__ inline float4 lda4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ inline float4 lda4<bf16_t>(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+template <typename AT> __device__ inline void sta4(AT* p, const float4& v);
+template <> __device__ inline void sta4<float>(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ inline void sta4<bf16_t>(bf16_t* p, const float4& v) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+template <typename AT> __device__ inline float lda1(const AT* p);
+template <> __device__ inline float lda1<float>(const float* p) { return *p; }
+template <> __device__ inline float lda1<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
 }  // namespace oct

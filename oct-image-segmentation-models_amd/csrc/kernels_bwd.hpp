@@ -17,15 +17,15 @@ namespace oct {
 // The encoder block's output y feeds (i) the pool and (ii) the decoder concat.  gskip already holds the
 // decoder's raw contribution; this kernel adds the pool's routed gradient, masks and emits the statistics.
 struct PoolBwdArgs {
-    const float* gp;   // (B,H/2,W/2,C) gradient wrt pooled tensor
-    const float* z;    // (B,H,W,C) block's raw output
+    const void* gp;    // (B,H/2,W/2,C) gradient wrt pooled tensor          (activation storage type)
+    const void* z;     // (B,H,W,C) block's raw output
     const float* bn;
-    float* g;          // (B,H,W,C): in = decoder contribution (raw), out = masked total
+    void* g;           // (B,H,W,C): in = decoder contribution (raw), out = masked total
     float* part;       // [B*tiles][2*C]   tiles over the POOLED grid
-    int H, W, C, tiles_x, tiles;
+    int H, W, C, tiles_x, tiles, act_bf16;
 };
 
-template <int C_T>
+template <int C_T, typename AT>
 __global__ __launch_bounds__(kBlock) void pool_bwd_k(const PoolBwdArgs A) {
     __shared__ float red[256];
     const int Ho = A.H >> 1, Wo = A.W >> 1;
@@ -40,17 +40,18 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_k(const PoolBwdArgs A) {
     if (valid) {
         // every tensor element is touched exactly once: z (4 positions), gp, g in, g out
         float gpv[C_T], zv[4][C_T], gd[4][C_T];
-        const float* gpp = A.gp + (((size_t)b * Ho + yo) * Wo + xo) * A.C + c0;
+        const AT* Az = reinterpret_cast<const AT*>(A.z); AT* Ag = reinterpret_cast<AT*>(A.g);
+        const AT* gpp = reinterpret_cast<const AT*>(A.gp) + (((size_t)b * Ho + yo) * Wo + xo) * A.C + c0;
 #pragma unroll
-        for (int i = 0; i < C_T; i += 4) { const float4 t = ld4(gpp + i); gpv[i] = t.x; gpv[i + 1] = t.y; gpv[i + 2] = t.z; gpv[i + 3] = t.w; }
+        for (int i = 0; i < C_T; i += 4) { const float4 t = lda4<AT>(gpp + i); gpv[i] = t.x; gpv[i + 1] = t.y; gpv[i + 2] = t.z; gpv[i + 3] = t.w; }
         size_t off[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             off[q] = (((size_t)b * A.H + 2 * yo + (q >> 1)) * A.W + 2 * xo + (q & 1)) * A.C + c0;
 #pragma unroll
             for (int i = 0; i < C_T; i += 4) {
-                const float4 t = ld4(A.z + off[q] + i); zv[q][i] = t.x; zv[q][i + 1] = t.y; zv[q][i + 2] = t.z; zv[q][i + 3] = t.w;
-                const float4 u = ld4(A.g + off[q] + i); gd[q][i] = u.x; gd[q][i + 1] = u.y; gd[q][i + 2] = u.z; gd[q][i + 3] = u.w;
+                const float4 t = lda4<AT>(Az + off[q] + i); zv[q][i] = t.x; zv[q][i + 1] = t.y; zv[q][i + 2] = t.z; zv[q][i + 3] = t.w;
+                const float4 u = lda4<AT>(Ag + off[q] + i); gd[q][i] = u.x; gd[q][i + 1] = u.y; gd[q][i + 2] = u.z; gd[q][i + 3] = u.w;
             }
         }
 #pragma unroll
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_k(const PoolBwdArgs A) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < C_T; i += 4) st4(A.g + off[q] + i, make_float4(gd[q][i], gd[q][i + 1], gd[q][i + 2], gd[q][i + 3]));
+            for (int i = 0; i < C_T; i += 4) sta4<AT>(Ag + off[q] + i, make_float4(gd[q][i], gd[q][i + 1], gd[q][i + 2], gd[q][i + 3]));
     }
     float* out = A.part + ((size_t)b * A.tiles + tile) * (2 * A.C);
     block_reduce_store<C_T>(s1, red, out + c0, C_T);
@@ -110,12 +111,13 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_finalize_k(const BnBwdFinArgs A
 }
 
 // dz = gamma*rstd*(g' - c1 - xhat*c2), in place over g'
-__global__ __launch_bounds__(kBlock) void bn_bwd_apply_k(float* __restrict__ g, const float* __restrict__ z,
+template <typename AT>
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_k(AT* __restrict__ g, const AT* __restrict__ z,
                                                         const float* __restrict__ bn, const float* __restrict__ gamma,
                                                         size_t n4, int C) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
         const int c = (int)((i * 4) % C);
-        const float4 gv = ld4(g + i * 4), zv = ld4(z + i * 4);
+        const float4 gv = lda4<AT>(g + i * 4), zv = lda4<AT>(z + i * 4);
         const float4 mean = ld4(bn + BN_MEAN * C + c), rstd = ld4(bn + BN_RSTD * C + c);
         const float4 c1 = ld4(bn + BN_C1 * C + c), c2 = ld4(bn + BN_C2 * C + c), gm = ld4(gamma + c);
         float4 o;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_k(float* __restrict__ g, 
         o.y = gm.y * rstd.y * (gv.y - c1.y - (zv.y - mean.y) * rstd.y * c2.y);
         o.z = gm.z * rstd.z * (gv.z - c1.z - (zv.z - mean.z) * rstd.z * c2.z);
         o.w = gm.w * rstd.w * (gv.w - c1.w - (zv.w - mean.w) * rstd.w * c2.w);
-        st4(g + i * 4, o);
+        sta4<AT>(g + i * 4, o);
     }
 }
 
@@ -132,17 +134,17 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_k(float* __restrict__ g, 
 // no dlogits tensor, no second read of z.  grid (nblk, B); a block walks chunks of one image and emits one row of
 // BN-backward statistics and one row of head-weight partials.
 struct HeadBwdArgs {
-    const float* z; const float* bn;     // last conv block
+    const void* z; const float* bn;      // last conv block (z: activation storage type)
     const float* w; const float* bias;   // head (CIN,C),(C)
     const unsigned char* labels;
     const double* bc;                    // Dice constants from dice_finalize_k
-    float* g;                            // (B,H,W,CIN) masked gradient of the last conv block
+    void* g;                             // (B,H,W,CIN) masked gradient of the last conv block (activation storage type)
     float* part;                         // [B*nblk][2*CIN]       BN-backward statistics
     float* wpart;                        // [B*nblk][CIN*C + C]   head kernel / bias gradient partials
-    int HW, nblk, B, macro; float loss_scale;
+    int HW, nblk, B, macro; float loss_scale; int act_bf16;
 };
 
-template <int C, int CIN>
+template <int C, int CIN, typename AT>
 __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
     constexpr int NV = CIN * C + C, NG = (NV + 31) / 32;
     __shared__ float red[256];
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
         const bool valid = px < A.HW;
         const size_t pix = (size_t)b * A.HW + (valid ? px : 0);
         float y[CIN], zr[CIN], p[C];
-        head_logits<C, CIN>(A.z + pix * CIN, A.bn, A.w, A.bias, y, zr, p);
+        head_logits<C, CIN, AT>(reinterpret_cast<const AT*>(A.z) + pix * CIN, A.bn, A.w, A.bias, y, zr, p);
         const int lab = A.labels[pix];
         float dp[C], dot = 0.f;
 #pragma unroll
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
         }
         if (valid) {
 #pragma unroll
-            for (int i = 0; i < CIN; i += 4) st4(A.g + pix * CIN + i, make_float4(g[i], g[i + 1], g[i + 2], g[i + 3]));
+            for (int i = 0; i < CIN; i += 4) sta4<AT>(reinterpret_cast<AT*>(A.g) + pix * CIN + i, make_float4(g[i], g[i + 1], g[i + 2], g[i + 3]));
         }
     }
     const size_t row = (size_t)b * gridDim.x + blockIdx.x;
@@ -209,12 +211,13 @@ __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
 // ---- conv backward-weights (LDS-staged tiles, per-block partial dW, deterministic second-stage sum) ------------
 struct ConvBwdWArgs {
     const void* x0; const float* ab0; int C0;   // conv input, same fetch semantics as the forward kernel
-    const float* x1; const float* ab1; int C1;
+    const void* x1; const float* ab1; int C1;
     int flags;                                  // F_* (runtime here: staging is outside the FMA loop)
-    const float* dz;                            // (B,H,W,Cout)
+    const void* dz;                             // (B,H,W,Cout), activation storage type
     float* part;                                // [npb][KH*KW*Cin*Cout + Cout]
     int B, H, W, Cin, Cout, tiles_x, tiles, total_tiles, npb;
     DropCfg drop;
+    int act_bf16;
 };
 
 __device__ __forceinline__ float fetch_x(const ConvBwdWArgs& A, int b, int iy, int ix, int c) {
@@ -225,7 +228,7 @@ __device__ __forceinline__ float fetch_x(const ConvBwdWArgs& A, int b, int iy, i
     const size_t pix = ((size_t)b * Hs + sy) * Ws + sx;
     if (A.flags & F_U8) return c_u8_lut[reinterpret_cast<const unsigned char*>(A.x0)[pix * A.C0 + c]];
     const float* src = reinterpret_cast<const float*>(A.x0); const float* ab = A.ab0; int C = A.C0, cc = c;
-    if ((A.flags & F_TWO) && c >= A.C0) { src = A.x1; ab = A.ab1; C = A.C1; cc = c - A.C0; }
+    if ((A.flags & F_TWO) && c >= A.C0) { src = reinterpret_cast<const float*>(A.x1); ab = A.ab1; C = A.C1; cc = c - A.C0; }
     float v = src[pix * C + cc];
     if (A.flags & F_AFF) v = fmaxf(fmaf(ab[cc], v, ab[C + cc]), 0.f);
     if (A.flags & F_DROP) v *= drop_mul(A.drop, (uint32_t)(pix * C + cc));
@@ -233,7 +236,8 @@ __device__ __forceinline__ float fetch_x(const ConvBwdWArgs& A, int b, int iy, i
 }
 
 // grid (npb, Cin/CI_T, ceil(Cout/CO_T)); thread t: entry e = t % (CI_T*CO_T) -> (ci, co); pixel split t / (CI_T*CO_T)
-template <int KH, int CI_T, int CO_T>
+// (VALU kernel: first layer only -- its input is the caller's image, its dz the first block's gradient)
+template <int KH, int CI_T, int CO_T, typename AT>
 __global__ __launch_bounds__(kBlock) void conv_bwd_w_k(const ConvBwdWArgs A) {
     constexpr int KW = KH, PT = (KH - 1) / 2, NT = CI_T * CO_T, PS = kBlock / NT, TAPS = KH * KW;
     constexpr int XH = kTileY + KH - 1, XW = kTileX + KW - 1;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void conv_bwd_w_k(const ConvBwdWArgs A) {
             const int c = i % CO_T, r = i / CO_T, cx = r % kTileX, cy = r / kTileX;
             const int oy = y0 + cy, ox = x0 + cx;
             float v = 0.f;
-            if (oy < A.H && ox < A.W && co0 + c < A.Cout) v = A.dz[(((size_t)b * A.H + oy) * A.W + ox) * A.Cout + co0 + c];
+            if (oy < A.H && ox < A.W && co0 + c < A.Cout) v = lda1<AT>(reinterpret_cast<const AT*>(A.dz) + (((size_t)b * A.H + oy) * A.W + ox) * A.Cout + co0 + c);
             Ds[i] = v;
         }
         __syncthreads();

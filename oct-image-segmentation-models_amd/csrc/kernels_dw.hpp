@@ -15,9 +15,10 @@ namespace oct {
 // tile t and written to LDS (with the consumer-side transform) after it, so HBM/L2 latency hides under compute ----
 
 // address part of the logical-input fetch: pointer to 4 consecutive channels (concat aware)
-__device__ __forceinline__ const float* x4_ptr(const ConvBwdWArgs& A, size_t pix, int c) {
-    if ((A.flags & F_TWO) && c >= A.C0) return A.x1 + pix * A.C1 + (c - A.C0);
-    return reinterpret_cast<const float*>(A.x0) + pix * A.C0 + c;
+template <typename AT>
+__device__ __forceinline__ const AT* x4_ptr(const ConvBwdWArgs& A, size_t pix, int c) {
+    if ((A.flags & F_TWO) && c >= A.C0) return reinterpret_cast<const AT*>(A.x1) + pix * A.C1 + (c - A.C0);
+    return reinterpret_cast<const AT*>(A.x0) + pix * A.C0 + c;
 }
 // transform part: BN+ReLU affine and dropout of the 4 loaded channels
 __device__ __forceinline__ float4 x4_xform(const ConvBwdWArgs& A, float4 v, size_t pix, int c) {
@@ -36,7 +37,7 @@ __device__ __forceinline__ float4 x4_xform(const ConvBwdWArgs& A, float4 v, size
     return v;
 }
 
-template <int CIC, int COC, int IH, int IW, bool UP, int KH, int TH>
+template <int CIC, int COC, int IH, int IW, bool UP, int KH, int TH, typename AT>
 struct TileStager {
     static constexpr int NX = (IH * IW * (CIC / 4) + kBlock - 1) / kBlock;   // float4 per thread, X tile
     static constexpr int ND = (TH * 32 * (COC / 4) + kBlock - 1) / kBlock;   // float4 per thread, dz tile
@@ -53,7 +54,7 @@ struct TileStager {
             const int gy = iy0 + ly, gx = ix0 + lx, c = ci0 + 4 * q;
             xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < IH * IW * (CIC / 4) && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws && c < A.Cin)
-                xr[k] = ld4(x4_ptr(A, ((size_t)b * Hs + gy) * Ws + gx, c));
+                xr[k] = lda4<AT>(x4_ptr<AT>(A, ((size_t)b * Hs + gy) * Ws + gx, c));
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
@@ -62,7 +63,7 @@ struct TileStager {
             const int oy = y0 + py, ox = x0 + px, c = co0 + 4 * q;
             dr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < TH * 32 * (COC / 4) && oy < A.H && ox < A.W && c < A.Cout)
-                dr[k] = ld4(A.dz + (((size_t)b * A.H + oy) * A.W + ox) * A.Cout + c);
+                dr[k] = lda4<AT>(reinterpret_cast<const AT*>(A.dz) + (((size_t)b * A.H + oy) * A.W + ox) * A.Cout + c);
         }
     }
     // write the loaded tile to LDS, applying the input transform; accumulates dz column sums (bias gradient)
@@ -113,7 +114,7 @@ __device__ __forceinline__ void bias_reduce(const ConvBwdWArgs& A, float* scratc
 // Every wave owns ALL M tiles for a quarter of the tile's pixel rows; 4-wave sum through LDS at the end.
 // grid (npb, ceil(Cin/CIC), ceil(Cout/16))
 // ---------------------------------------------------------------------------------------------------------------
-template <int KH, int CIC, bool UP>
+template <int KH, int CIC, bool UP, typename AT>
 __global__ __launch_bounds__(kBlock) void conv_dw16_k(const ConvBwdWArgs A) {
     constexpr int TH = 8, TW = 32, TAPS = KH * KH, MROWS = TAPS * CIC, MTILES = (MROWS + 15) / 16;
     constexpr int IH = UP ? TH / 2 + 1 : TH + KH - 1, IW = UP ? TW / 2 + 1 : TW + KH - 1;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void conv_dw16_k(const ConvBwdWArgs A) {
     for (int mt = 0; mt < MTILES; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    TileStager<CIC, 16, IH, IW, UP, KH, TH> st;
+    TileStager<CIC, 16, IH, IW, UP, KH, TH, AT> st;
     auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
         b = tl / A.tiles; const int tile = tl % A.tiles;
         x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void conv_dw16_k(const ConvBwdWArgs A) {
 // The (ci-tile, tap) units are dealt round-robin to the 4 waves; every wave sweeps all pixels of the tile for
 // its own units, so no cross-wave reduction is needed.   grid (npb, Cin/CIC, Cout/32)
 // ---------------------------------------------------------------------------------------------------------------
-template <int KH, int CIC, bool UP, int TH>
+template <int KH, int CIC, bool UP, int TH, typename AT>
 __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
     constexpr int TW = 32, COC = 32, TAPS = KH * KH, MTB = CIC / 32, UNITS = MTB * TAPS, UPW = (UNITS + 3) / 4;
     constexpr int IH = UP ? TH / 2 + 1 : TH + KH - 1, IW = UP ? TW / 2 + 1 : TW + KH - 1;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    TileStager<CIC, COC, IH, IW, UP, KH, TH> st;
+    TileStager<CIC, COC, IH, IW, UP, KH, TH, AT> st;
     auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
         b = tl / A.tiles; const int tile = tl % A.tiles;
         x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;

@@ -18,10 +18,11 @@ struct ConvFwdArgs {
     int C1;
     const float* w;    // (KH,KW,Cin,Cout) HWIO
     const float* bias; // (Cout)
-    float* z;          // (B,H,W,Cout)
+    void* z;           // (B,H,W,Cout), activation storage type
     float* part;       // [B*tiles][2*Cout] stat partials or nullptr
     int H, W, Cin, Cout, tiles_x, tiles;
     DropCfg drop;
+    int act_bf16;      // activation storage type selector for the launcher
 };
 
 // acc[j] += sum_c f(src[pix][c]) * w[c][j]   (w row stride = Cout; all weight addresses wave-uniform)
@@ -75,7 +76,7 @@ __device__ inline void accum_src(const void* __restrict__ src, const float* __re
 }
 
 // One thread = one output pixel x CO_T output channels.  grid (tiles, Cout/CO_T, B), block 256.
-template <int KH, int CO_T, int FLAGS>
+template <int KH, int CO_T, int FLAGS, typename AT>
 __global__ __launch_bounds__(kBlock) void conv_fwd_k(const ConvFwdArgs A) {
     constexpr int KW = KH, PT = (KH - 1) / 2;
     constexpr bool TWO = (FLAGS & F_TWO) != 0, UP = (FLAGS & F_UP) != 0;
@@ -104,9 +105,9 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_k(const ConvFwdArgs A) {
         }
     }
     if (valid) {
-        float* zp = A.z + (((size_t)b * A.H + y) * A.W + x) * A.Cout + co0;
+        AT* zp = reinterpret_cast<AT*>(A.z) + (((size_t)b * A.H + y) * A.W + x) * A.Cout + co0;
 #pragma unroll
-        for (int j = 0; j < CO_T; j += 4) st4(zp + j, make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]));
+        for (int j = 0; j < CO_T; j += 4) sta4<AT>(zp + j, make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]));
     }
     if (A.part) {  // per-block BatchNorm statistics of this conv's own output
         float s[CO_T], q[CO_T];
@@ -190,8 +191,9 @@ __global__ void bn_infer_all_k(const BnInferAll A, float eps) {
 }
 
 // ---- max-pool 2x2 with BN+ReLU fused on load: p = max over window of relu(a*z+b) -------------------------
-__global__ __launch_bounds__(kBlock) void pool_fwd_k(const float* __restrict__ z, const float* __restrict__ ab,
-                                                    float* __restrict__ p, int B, int H, int W, int C) {
+template <typename AT>
+__global__ __launch_bounds__(kBlock) void pool_fwd_k(const AT* __restrict__ z, const float* __restrict__ ab,
+                                                    AT* __restrict__ p, int B, int H, int W, int C) {
     // H, W: INPUT dims.  one thread = one pooled pixel x 4 channels
     const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
     const size_t n = (size_t)B * Ho * Wo * C4;
@@ -206,11 +208,11 @@ __global__ __launch_bounds__(kBlock) void pool_fwd_k(const float* __restrict__ z
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                const float4 v = ld4(z + (((size_t)b * H + 2 * yo + dy) * W + 2 * xo + dx) * C + c);
+                const float4 v = lda4<AT>(z + (((size_t)b * H + 2 * yo + dy) * W + 2 * xo + dx) * C + c);
                 m.x = fmaxf(m.x, fmaf(a.x, v.x, bb.x)); m.y = fmaxf(m.y, fmaf(a.y, v.y, bb.y));
                 m.z = fmaxf(m.z, fmaf(a.z, v.z, bb.z)); m.w = fmaxf(m.w, fmaf(a.w, v.w, bb.w));
             }
-        st4(p + (((size_t)b * Ho + yo) * Wo + xo) * C + c, m);
+        sta4<AT>(p + (((size_t)b * Ho + yo) * Wo + xo) * C + c, m);
     }
 }
 
@@ -219,20 +221,20 @@ constexpr int kDiceVals = 5;  // per class: I = sum y*p, T = sum y, P = sum p, I
 template <int C> struct DiceN { static constexpr int value = (5 * C <= 16) ? 16 : (5 * C <= 32 ? 32 : 64); };
 
 struct HeadFwdArgs {
-    const float* z; const float* ab;   // last conv's raw output + BN record
+    const void* z; const float* ab;    // last conv's raw output (activation storage type) + BN record
     const float* w; const float* bias; // (CIN, C), (C)
     float* probs; unsigned char* argmax; const unsigned char* labels;
     float* dice_part;                  // [B][nblk][DiceN]
-    int HW, nblk;
+    int HW, nblk, act_bf16;
 };
 
-template <int C, int CIN>
-__device__ inline void head_logits(const float* __restrict__ zp, const float* __restrict__ ab,
+template <int C, int CIN, typename AT>
+__device__ inline void head_logits(const AT* __restrict__ zp, const float* __restrict__ ab,
                                    const float* __restrict__ w, const float* __restrict__ bias,
                                    float (&y)[CIN], float (&zr)[CIN], float (&p)[C]) {
 #pragma unroll
     for (int i = 0; i < CIN; i += 4) {
-        const float4 v = ld4(zp + i);
+        const float4 v = lda4<AT>(zp + i);
         zr[i] = v.x; zr[i + 1] = v.y; zr[i + 2] = v.z; zr[i + 3] = v.w;
     }
 #pragma unroll
@@ -255,7 +257,7 @@ __device__ inline void head_logits(const float* __restrict__ zp, const float* __
 
 // grid (nblk, B): each block walks the 256-pixel chunks  blockIdx.x, blockIdx.x + nblk, ...  of ONE image and emits
 // one row of Dice partial sums
-template <int C, int CIN>
+template <int C, int CIN, typename AT>
 __global__ __launch_bounds__(kBlock) void head_fwd_k(const HeadFwdArgs A) {
     constexpr int N = DiceN<C>::value;
     __shared__ float red[256];
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void head_fwd_k(const HeadFwdArgs A) {
         const bool valid = px < A.HW;
         const size_t pix = (size_t)b * A.HW + (valid ? px : 0);
         float y[CIN], zr[CIN], p[C];
-        head_logits<C, CIN>(A.z + pix * CIN, A.ab, A.w, A.bias, y, zr, p);
+        head_logits<C, CIN, AT>(reinterpret_cast<const AT*>(A.z) + pix * CIN, A.ab, A.w, A.bias, y, zr, p);
         if (valid) {
             if (A.probs) {
 #pragma unroll

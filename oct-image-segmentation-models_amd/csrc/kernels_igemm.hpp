@@ -27,17 +27,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct IgemmArgs {
-    const float* x0; const float* ab0; int C0;   // input source 0 (+ BN record when F_AFF)
-    const float* x1; const float* ab1; int C1;   // source 1 of a concat (F_TWO)
+    const void* x0; const float* ab0; int C0;    // input source 0 (activation storage type; + BN record when F_AFF)
+    const void* x1; const float* ab1; int C1;    // source 1 of a concat (F_TWO)
     int flags;                                   // F_AFF | F_TWO | F_DROP   (runtime: staging is not the hot loop)
     int Cin;                                     // K channels in total
     const float* w; int w_ld; int m_off;         // weights [taps][Cin][w_ld]; this launch covers columns m_off..m_off+Mout
     const float* bias;                           // EPI_FWD
-    float* out; int Mout;                        // (B,Ho,Wo,Mout)
+    void* out; int Mout;                         // (B,Ho,Wo,Mout), activation storage type
     int Ho, Wo, Hi, Wi;                          // output / input-source spatial dims
     int tiles_x, tiles, total_tiles;            // total_tiles = B * tiles (persistent variant)
     float* part;                                 // [B*tiles][2*Mout] statistic partials (EPI_FWD / EPI_MASK) or nullptr
-    const float* zin; const float* bnin;         // EPI_MASK: producer's raw output (B,Ho,Wo,Mout) + its BN record
+    const void* zin; const float* bnin;          // EPI_MASK: producer's raw output (B,Ho,Wo,Mout) + its BN record
+    int act_bf16;                                // activation storage type selector for the launchers
     int drop_out;                                // EPI_MASK: the producer's output passes through dropout
     DropCfg drop;
 };
@@ -136,7 +137,7 @@ __device__ __forceinline__ void mfma_sweep(const float* __restrict__ Ws, const f
 }
 
 // grid (tiles, ceil(Mout/MB), B), block 256 = 4 waves arranged WN (pixel tiles) x WM (channel tiles)
-template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN>
+template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN, typename AT>
 __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
     using S = MfmaShape<SHAPE>;
     constexpr int MT = SHAPE, NT = SHAPE, KS = S::KS, ACC = S::ACC, QUADS = S::QUADS;
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
             pin[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < (KC / 4) * IH * IW && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
                 const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
-                pin[k] = ld4(((A.flags & F_TWO) && c >= A.C0) ? A.x1 + pix * A.C1 + (c - A.C0) : A.x0 + pix * A.C0 + c);
+                pin[k] = lda4<AT>(((A.flags & F_TWO) && c >= A.C0) ? reinterpret_cast<const AT*>(A.x1) + pix * A.C1 + (c - A.C0)
+                                                                  : reinterpret_cast<const AT*>(A.x0) + pix * A.C0 + c);
             }
         }
 #pragma unroll
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
                         s1[mt][4 * q + k] += u; s2[mt][4 * q + k] += u * u;
                     }
                 } else if constexpr (EPI == EPI_MASK) {
-                    const float4 zq = valid ? ld4(A.zin + pix * A.Mout + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 zq = valid ? lda4<AT>(reinterpret_cast<const AT*>(A.zin) + pix * A.Mout + m) : make_float4(0.f, 0.f, 0.f, 0.f);
                     const float zz[4] = {zq.x, zq.y, zq.z, zq.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
                         v[k] = gv; s1[mt][4 * q + k] += gv; s2[mt][4 * q + k] += gv * xh;
                     }
                 }
-                if (valid) st4(A.out + pix * A.Mout + m, make_float4(v[0], v[1], v[2], v[3]));
+                if (valid) sta4<AT>(reinterpret_cast<AT*>(A.out) + pix * A.Mout + m, make_float4(v[0], v[1], v[2], v[3]));
             }
         }
     }
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
 //   * BN statistics accumulate in registers across all tiles of the block; ONE partial row per block.
 // grid (nblk, ceil(Mout/MB), 1); A.tiles = pixel tiles per image, A.total_tiles = B * A.tiles.
 // ------------------------------------------------------------------------------------------------------------------
-template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN, int KCP>
+template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN, int KCP, typename AT>
 __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
     using S = MfmaShape<SHAPE>;
     constexpr int MT = SHAPE, NT = SHAPE, KS = S::KS, ACC = S::ACC, QUADS = S::QUADS;
@@ -393,8 +395,9 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
             pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < (KCP / 4) * IH * IW && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
                 const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
-                const float* src = ((A.flags & F_TWO) && c >= A.C0) ? A.x1 + pix * A.C1 + (c - A.C0) : A.x0 + pix * A.C0 + c;
-                pf[k] = ld4(src);
+                const AT* src = ((A.flags & F_TWO) && c >= A.C0) ? reinterpret_cast<const AT*>(A.x1) + pix * A.C1 + (c - A.C0)
+                                                                  : reinterpret_cast<const AT*>(A.x0) + pix * A.C0 + c;
+                pf[k] = lda4<AT>(src);
             }
         }
     };
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
 #pragma unroll
                     for (int q = 0; q < QUADS; ++q) {
                         const int m = m0 + (wm * MTW + mt) * MT + S::quad_base(q, h);
-                        zq[nt][mt][q] = (pvalid && m < A.Mout) ? ld4(A.zin + pix * A.Mout + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        zq[nt][mt][q] = (pvalid && m < A.Mout) ? lda4<AT>(reinterpret_cast<const AT*>(A.zin) + pix * A.Mout + m) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
             }
         }
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
                             v[k] = gv; s1[mt][4 * q + k] += gv; s2[mt][4 * q + k] += gv * xh;
                         }
                     }
-                    if (valid) st4(A.out + pix * A.Mout + m, make_float4(v[0], v[1], v[2], v[3]));
+                    if (valid) sta4<AT>(reinterpret_cast<AT*>(A.out) + pix * A.Mout + m, make_float4(v[0], v[1], v[2], v[3]));
                 }
             }
         }

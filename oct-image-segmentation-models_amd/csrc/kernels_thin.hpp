@@ -15,8 +15,8 @@
 namespace oct {
 
 // grid (nblk, 1, 1); requires Mout == 8, Cin <= 16 (Cin % 4 == 0), AMODE in {A_NORMAL (KH=3), A_UPF (KH=2)}
-template <int KH, int AMODE, int EPI, int CMAX>
-__global__ __launch_bounds__(kBlock) void conv_thin8_k(const IgemmArgs A, const float* __restrict__ wgt, float* __restrict__ outp) {
+template <int KH, int AMODE, int EPI, int CMAX, typename AT>
+__global__ __launch_bounds__(kBlock) void conv_thin8_k(const IgemmArgs A, const float* __restrict__ wgt, AT* __restrict__ outp) {
     constexpr int TH = 8, TW = 64, M = 8, PX = 2;
     constexpr int IH = AMODE == A_NORMAL ? TH + KH - 1 : TH / 2 + 1;
     constexpr int IW = AMODE == A_NORMAL ? TW + KH - 1 : TW / 2 + 1;
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(kBlock) void conv_thin8_k(const IgemmArgs A, const 
             pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < (CMAX / 4) * IH * IW && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
                 const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
-                pf[k] = ld4(((A.flags & F_TWO) && c >= A.C0) ? A.x1 + pix * A.C1 + (c - A.C0) : A.x0 + pix * A.C0 + c);
+                pf[k] = lda4<AT>(((A.flags & F_TWO) && c >= A.C0) ? reinterpret_cast<const AT*>(A.x1) + pix * A.C1 + (c - A.C0)
+                                                                 : reinterpret_cast<const AT*>(A.x0) + pix * A.C0 + c);
             }
         }
     };
@@ -102,9 +103,9 @@ __global__ __launch_bounds__(kBlock) void conv_thin8_k(const IgemmArgs A, const 
 #pragma unroll
             for (int p = 0; p < PX; ++p) {
                 const bool ok = rowok && x + p < A.Wo;
-                const float* zp = A.zin + (((size_t)b * A.Ho + (ok ? y : 0)) * A.Wo + (ok ? x + p : 0)) * M;
-                zq[p][0] = ok ? ld4(zp) : make_float4(0.f, 0.f, 0.f, 0.f);
-                zq[p][1] = ok ? ld4(zp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const AT* zp = reinterpret_cast<const AT*>(A.zin) + (((size_t)b * A.Ho + (ok ? y : 0)) * A.Wo + (ok ? x + p : 0)) * M;
+                zq[p][0] = ok ? lda4<AT>(zp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                zq[p][1] = ok ? lda4<AT>(zp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 
@@ -182,8 +183,8 @@ __global__ __launch_bounds__(kBlock) void conv_thin8_k(const IgemmArgs A, const 
                 }
             }
             if (valid) {
-                st4(outp + pix * M, make_float4(v[0], v[1], v[2], v[3]));
-                st4(outp + pix * M + 4, make_float4(v[4], v[5], v[6], v[7]));
+                sta4<AT>(outp + pix * M, make_float4(v[0], v[1], v[2], v[3]));
+                sta4<AT>(outp + pix * M + 4, make_float4(v[4], v[5], v[6], v[7]));
             }
         }
     }

@@ -56,6 +56,10 @@ struct ProfScope {
     ~ProfScope() { if (p) (void)hipEventRecord(p->recs[idx].e1, s); }
 };
 
+// run a launch statement with `AT` bound to the activation storage type
+#define AT_DISPATCH(bf, ...) do { if (bf) { using AT = bf16_t; __VA_ARGS__; } else { using AT = float; __VA_ARGS__; } } while (0)
+#define AT_NAME(bf) ((bf) ? "unsigned short" : "float")
+
 enum Src { SRC_INPUT, SRC_PREV, SRC_POOL, SRC_UP, SRC_CONCAT, SRC_HEAD };
 
 struct Layer {
@@ -63,7 +67,8 @@ struct Layer {
     int kh, kw, cin, cout, level, H, W, has_bn, src, skip_from, drop_in;
     size_t w_off, b_off, gamma_off, beta_off, mm_off, mv_off;
     // workspace (device) pointers
-    float* z = nullptr; float* g = nullptr; float* bn = nullptr;
+    void* z = nullptr; void* g = nullptr;   // activation storage type (f32 or bf16)
+    float* bn = nullptr;
     float* dwp = nullptr;  // this layer's dW slabs [npb][kh*kw*cin*cout + cout]
     float* wt = nullptr;   // backward-data weights: transposed+flipped 3x3, or effective 3x3 of an up-conv (9*cin*cout)
 };
@@ -87,7 +92,7 @@ int check_cfg(const oct_unet_cfg* c) {
     const int m = 1 << c->pool_layers;
     if (c->H < m || c->W < m || c->H % m || c->W % m) return fail(-1, "H and W must be multiples of 2^pool_layers");
     if (c->max_batch < 1) return fail(-1, "max_batch must be >= 1");
-    if (c->dtype != 0) return fail(-2, "dtype: only 0 (f32) is implemented");
+    if (c->dtype != 0 && c->dtype != 1) return fail(-2, "dtype must be 0 (f32) or 1 (bf16 activation storage, f32 arithmetic)");
     if (!(c->dropout_rate >= 0.f && c->dropout_rate < 1.f)) return fail(-1, "dropout_rate must be in [0,1)");
     if (c->pool_layers * (2 * c->conv_layers + 1) + c->conv_layers + 1 > ReduceAllArgs::MAXL)
         return fail(-1, "too many conv layers (pool_layers*(2*conv_layers+1)+conv_layers+1 must be <= 40)");
@@ -178,7 +183,7 @@ struct oct_unet {
     oct_unet_cfg cfg;
     Plan plan;
     float* params; float* grads; float* state;
-    std::vector<float*> pooled, gpooled;   // per encoder level
+    std::vector<void*> pooled, gpooled;    // per encoder level (activation storage type)
     float* stat_part = nullptr;            // BN statistic partials (fwd and bwd share it: stream-ordered)
     ReduceAllArgs red{};                   // filled while backward runs; one reduce launch at the end
     float* dice_part = nullptr; double* dice_bc = nullptr; float* loss4 = nullptr;
@@ -196,12 +201,12 @@ namespace {
 size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
     size_t off = 0;
     auto take = [&](size_t bytes) -> char* { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
-    const size_t B = (size_t)c.max_batch;
+    const size_t B = (size_t)c.max_batch, esz = c.dtype ? 2 : 4;   // bytes per stored activation element
     size_t stat_max = 0, dw_max = 0;
     for (auto& l : pl.L) {
         const size_t n = B * l.H * l.W * l.cout;
-        float* z = l.has_bn ? (float*)take(n * 4) : nullptr;   // the head writes straight to the caller's buffers
-        float* g = c.training && l.has_bn ? (float*)take(n * 4) : nullptr;
+        void* z = l.has_bn ? (void*)take(n * esz) : nullptr;   // the head writes straight to the caller's buffers
+        void* g = c.training && l.has_bn ? (void*)take(n * esz) : nullptr;
         float* bn = l.has_bn ? (float*)take((size_t)BN_ARRAYS * l.cout * 4) : nullptr;
         float* wt = (c.training && l.has_bn && l.src != SRC_INPUT) ? (float*)take((size_t)9 * l.cin * l.cout * 4) : nullptr;
         if (base) { l.z = z; l.g = g; l.bn = bn; l.wt = wt; }
@@ -217,8 +222,8 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
     }
     for (int i = 0; i < pl.P; ++i) {
         const size_t n = B * (c.H >> (i + 1)) * (c.W >> (i + 1)) * ((size_t)c.start_neurons << i);
-        float* p = (float*)take(n * 4);
-        float* gp = c.training ? (float*)take(n * 4) : nullptr;
+        void* p = (void*)take(n * esz);
+        void* gp = c.training ? (void*)take(n * esz) : nullptr;
         if (h) { h->pooled.push_back(p); h->gpooled.push_back(gp); }
     }
     const int nblk_head = cdiv(c.H * c.W, kBlock);
@@ -249,19 +254,19 @@ template <int KH, int FLAGS>
 int launch_conv_fwd_co(const ConvFwdArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes) {
     const int co_t = chunk_of(a.Cout);
     dim3 grid(a.tiles, a.Cout / co_t, B), block(kBlock);
-    char nm[48]; snprintf(nm, sizeof nm, "conv_fwd_k<%d,%d,%d>", KH, co_t, FLAGS);
+    char nm[64]; snprintf(nm, sizeof nm, "conv_fwd_k<%d,%d,%d,%s>", KH, co_t, FLAGS, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, layer, flops, bytes);
     switch (co_t) {
-        case 16: conv_fwd_k<KH, 16, FLAGS><<<grid, block, 0, s>>>(a); break;
-        case 8: conv_fwd_k<KH, 8, FLAGS><<<grid, block, 0, s>>>(a); break;
-        default: conv_fwd_k<KH, 4, FLAGS><<<grid, block, 0, s>>>(a); break;
+        case 16: AT_DISPATCH(a.act_bf16, conv_fwd_k<KH, 16, FLAGS, AT><<<grid, block, 0, s>>>(a)); break;
+        case 8: AT_DISPATCH(a.act_bf16, conv_fwd_k<KH, 8, FLAGS, AT><<<grid, block, 0, s>>>(a)); break;
+        default: AT_DISPATCH(a.act_bf16, conv_fwd_k<KH, 4, FLAGS, AT><<<grid, block, 0, s>>>(a)); break;
     }
     HIP_OK(hipGetLastError());
     return 0;
 }
 
 // source description of layer li's input (shared by forward conv and dW)
-struct SrcDesc { const void* x0; const float* ab0; int C0; const float* x1; const float* ab1; int C1; int flags; };
+struct SrcDesc { const void* x0; const float* ab0; int C0; const void* x1; const float* ab1; int C1; int flags; };
 
 SrcDesc src_of(const oct_unet* h, int li, const void* x_in, int x_is_u8) {
     const Layer& l = h->plan.L[li];
@@ -284,9 +289,9 @@ template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN>
 int launch_igemm_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
     a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH);
     dim3 grid(a.tiles, cdiv(a.Mout, MB), B), block(kBlock);
-    char nm[48]; snprintf(nm, sizeof nm, "conv_igemm_k<%d,%d,%d,%d,%d,%d,%d>", SHAPE, KH, AMODE, EPI, TH, MB, WN);
+    char nm[64]; snprintf(nm, sizeof nm, "conv_igemm_k<%d,%d,%d,%d,%d,%d,%d,%s>", SHAPE, KH, AMODE, EPI, TH, MB, WN, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, layer, flops, bytes);
-    conv_igemm_k<SHAPE, KH, AMODE, EPI, TH, MB, WN><<<grid, block, 0, s>>>(a);
+    AT_DISPATCH(a.act_bf16, conv_igemm_k<SHAPE, KH, AMODE, EPI, TH, MB, WN, AT><<<grid, block, 0, s>>>(a));
     HIP_OK(hipGetLastError());
     *rows = B * a.tiles;   // one statistic partial row per (image, pixel tile)
     return 0;
@@ -298,9 +303,9 @@ int launch_igemm_p(IgemmArgs a, int B, hipStream_t s, const char* layer, double 
     a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH); a.total_tiles = B * a.tiles;
     const int nblk = std::min(a.total_tiles, 1280);    // ~5 resident blocks per CU
     dim3 grid(nblk, cdiv(a.Mout, MB), 1), block(kBlock);
-    char nm[48]; snprintf(nm, sizeof nm, "conv_igemm_p_k<%d,%d,%d,%d,%d,%d,%d,%d>", SHAPE, KH, AMODE, EPI, TH, MB, WN, KCP);
+    char nm[64]; snprintf(nm, sizeof nm, "conv_igemm_p_k<%d,%d,%d,%d,%d,%d,%d,%d,%s>", SHAPE, KH, AMODE, EPI, TH, MB, WN, KCP, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, layer, flops, bytes);
-    conv_igemm_p_k<SHAPE, KH, AMODE, EPI, TH, MB, WN, KCP><<<grid, block, 0, s>>>(a);
+    AT_DISPATCH(a.act_bf16, conv_igemm_p_k<SHAPE, KH, AMODE, EPI, TH, MB, WN, KCP, AT><<<grid, block, 0, s>>>(a));
     HIP_OK(hipGetLastError());
     *rows = nblk;       // one statistic partial row per block
     return 0;
@@ -311,10 +316,10 @@ template <int KH, int AMODE, int EPI>
 int launch_thin8(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
     a.tiles_x = cdiv(a.Wo, 64); a.tiles = a.tiles_x * cdiv(a.Ho, 8); a.total_tiles = B * a.tiles;
     const int nblk = std::min(a.total_tiles, 1536);
-    char nm[48]; snprintf(nm, sizeof nm, "conv_thin8_k<%d,%d,%d,%d>", KH, AMODE, EPI, a.Cin <= 8 ? 8 : 16);
+    char nm[64]; snprintf(nm, sizeof nm, "conv_thin8_k<%d,%d,%d,%d,%s>", KH, AMODE, EPI, a.Cin <= 8 ? 8 : 16, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, layer, flops, bytes);
-    if (a.Cin <= 8) conv_thin8_k<KH, AMODE, EPI, 8><<<nblk, kBlock, 0, s>>>(a, a.w, a.out);
-    else conv_thin8_k<KH, AMODE, EPI, 16><<<nblk, kBlock, 0, s>>>(a, a.w, a.out);
+    if (a.Cin <= 8) AT_DISPATCH(a.act_bf16, conv_thin8_k<KH, AMODE, EPI, 8, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
+    else AT_DISPATCH(a.act_bf16, conv_thin8_k<KH, AMODE, EPI, 16, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
     HIP_OK(hipGetLastError());
     *rows = nblk;
     return 0;
@@ -347,35 +352,36 @@ int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, do
 
 // algorithmic bytes of a conv's logical input, read once: low-res tensor for an up-conv, both
 // halves of a concat, the pooled tensor after a pool, 1 B/px for a u8 image
-double in_bytes(const Layer& l, int B, int x_is_u8) {
+double in_bytes(const Layer& l, int B, int x_is_u8, int es = 4) {
     const double px = (double)B * l.H * l.W;
     if (l.src == SRC_INPUT) return px * l.cin * (x_is_u8 ? 1 : 4);
-    if (l.src == SRC_UP) return px / 4 * l.cin * 4;
-    return px * l.cin * 4;
+    if (l.src == SRC_UP) return px / 4 * l.cin * es;
+    return px * l.cin * es;
 }
 
 int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int training, hipStream_t s) {
     Layer& l = h->plan.L[li];
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
     ConvFwdArgs a{};
-    a.x0 = sd.x0; a.ab0 = sd.ab0; a.C0 = sd.C0; a.x1 = sd.x1; a.ab1 = sd.ab1; a.C1 = sd.C1;
+    a.x0 = sd.x0; a.ab0 = sd.ab0; a.C0 = sd.C0; a.x1 = nullptr; a.ab1 = nullptr; a.C1 = 0;   // VALU kernel: first layer only
     a.w = h->params + l.w_off; a.bias = h->params + l.b_off; a.z = l.z;
     a.part = (training && l.has_bn) ? h->stat_part : nullptr;
     a.H = l.H; a.W = l.W; a.Cin = l.cin; a.Cout = l.cout;
     a.tiles_x = cdiv(l.W, kTileX); a.tiles = tiles_of(l.H, l.W);
-    a.drop = make_drop(h);
+    a.drop = make_drop(h); a.act_bf16 = h->cfg.dtype;
     const bool drop = training && l.drop_in;
     const double px = (double)B * l.H * l.W, fl = 2.0 * l.kh * l.kw * l.cin * l.cout * px;
-    const double by = in_bytes(l, B, x_is_u8) + px * l.cout * 4;   // logical input once + output once
+    const int es = h->cfg.dtype ? 2 : 4;
+    const double by = in_bytes(l, B, x_is_u8, es) + px * l.cout * es;   // logical input once + output once
     int rc;
     int stat_rows = B * a.tiles;
     if (l.src != SRC_INPUT && l.cin % 4 == 0) {   // MFMA path (every conv except the 1-channel first layer)
         IgemmArgs g{};
-        g.x0 = (const float*)sd.x0; g.ab0 = sd.ab0; g.C0 = sd.C0; g.x1 = sd.x1; g.ab1 = sd.ab1; g.C1 = sd.C1;
+        g.x0 = sd.x0; g.ab0 = sd.ab0; g.C0 = sd.C0; g.x1 = sd.x1; g.ab1 = sd.ab1; g.C1 = sd.C1;
         g.flags = sd.flags | (drop ? F_DROP : 0);
         g.Cin = l.cin; g.w = a.w; g.w_ld = l.cout; g.m_off = 0; g.bias = a.bias; g.out = l.z; g.Mout = l.cout;
         g.Ho = l.H; g.Wo = l.W; g.Hi = l.src == SRC_UP ? l.H / 2 : l.H; g.Wi = l.src == SRC_UP ? l.W / 2 : l.W;
-        g.part = a.part; g.drop = a.drop;
+        g.part = a.part; g.drop = a.drop; g.act_bf16 = h->cfg.dtype;
         rc = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows)
                              : launch_igemm<3, A_NORMAL, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows);
     } else if (l.src == SRC_INPUT) {   // first layer: 1 (or odd) input channels, uint8 /255 table on load -> VALU direct conv
@@ -401,12 +407,12 @@ template <int C>
 int launch_head_fwd(const HeadFwdArgs& a, int cin, int B, hipStream_t s) {
     dim3 grid(a.nblk, B), block(kBlock);
     const double px = (double)B * a.HW;
-    char nm[48]; snprintf(nm, sizeof nm, "head_fwd_k<%d,%d>", C, cin);
+    char nm[64]; snprintf(nm, sizeof nm, "head_fwd_k<%d,%d,%s>", C, cin, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, "head", 2.0 * cin * C * px, px * (cin * 4 + (a.probs ? C * 4 : 0) + (a.argmax ? 1 : 0) + (a.labels ? 1 : 0)));
     switch (cin) {
-        case 4: head_fwd_k<C, 4><<<grid, block, 0, s>>>(a); break;
-        case 8: head_fwd_k<C, 8><<<grid, block, 0, s>>>(a); break;
-        case 16: head_fwd_k<C, 16><<<grid, block, 0, s>>>(a); break;
+        case 4: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 4, AT><<<grid, block, 0, s>>>(a)); break;
+        case 8: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 8, AT><<<grid, block, 0, s>>>(a)); break;
+        case 16: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 16, AT><<<grid, block, 0, s>>>(a)); break;
         default: return fail(-3, "head: unsupported start_neurons");
     }
     HIP_OK(hipGetLastError());
@@ -417,12 +423,12 @@ template <int C>
 int launch_head_bwd(const HeadBwdArgs& a, int cin, int B, hipStream_t s) {
     dim3 grid(a.nblk, B), block(kBlock);
     const double px = (double)B * a.HW;
-    char nm[48]; snprintf(nm, sizeof nm, "head_bwd_k<%d,%d>", C, cin);
+    char nm[64]; snprintf(nm, sizeof nm, "head_bwd_k<%d,%d,%s>", C, cin, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, "head", 6.0 * cin * C * px, px * (cin * 4 * 2 + 1));
     switch (cin) {
-        case 4: head_bwd_k<C, 4><<<grid, block, 0, s>>>(a); break;
-        case 8: head_bwd_k<C, 8><<<grid, block, 0, s>>>(a); break;
-        case 16: head_bwd_k<C, 16><<<grid, block, 0, s>>>(a); break;
+        case 4: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 4, AT><<<grid, block, 0, s>>>(a)); break;
+        case 8: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 8, AT><<<grid, block, 0, s>>>(a)); break;
+        case 16: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 16, AT><<<grid, block, 0, s>>>(a)); break;
         default: return fail(-3, "head: unsupported start_neurons");
     }
     HIP_OK(hipGetLastError());
@@ -469,8 +475,9 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
             const Layer& p = pl.L[li - 1];
             const size_t n = (size_t)B * (p.H / 2) * (p.W / 2) * (p.cout / 4);
             const int grid = (int)std::min<size_t>((n + kBlock - 1) / kBlock, 8192);
-            ProfScope ps(s, "pool_fwd_k", p.name, 0, (double)n * 16 * 5);   // read 4 px, write 1
-            pool_fwd_k<<<grid, kBlock, 0, s>>>(p.z, p.bn, h->pooled[l.level - 1], B, p.H, p.W, p.cout);
+            const int bf = h->cfg.dtype;
+            ProfScope ps(s, bf ? "pool_fwd_k<unsigned short>" : "pool_fwd_k<float>", p.name, 0, (double)n * (bf ? 8 : 16) * 5);   // read 4 px, write 1
+            AT_DISPATCH(bf, pool_fwd_k<AT><<<grid, kBlock, 0, s>>>((const AT*)p.z, p.bn, (AT*)h->pooled[l.level - 1], B, p.H, p.W, p.cout));
             HIP_OK(hipGetLastError());
         }
         const int rc = conv_forward(h, li, x, x_is_u8, B, training, s);
@@ -481,7 +488,7 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
     HeadFwdArgs a{};
     a.z = last.z; a.ab = last.bn; a.w = h->params + hd.w_off; a.bias = h->params + hd.b_off;
     a.probs = io ? io->probs : nullptr; a.argmax = io ? io->argmax : nullptr; a.labels = io ? io->labels : nullptr;
-    a.dice_part = h->dice_part; a.HW = hd.H * hd.W; a.nblk = head_nblk(a.HW, B);
+    a.dice_part = h->dice_part; a.HW = hd.H * hd.W; a.nblk = head_nblk(a.HW, B); a.act_bf16 = h->cfg.dtype;
     const int rc = DISPATCH_C(launch_head_fwd, h->cfg.n_cls, a, hd.cin, B, s);
     if (rc) return rc;
     h->last_B = B; h->last_training = training; h->have_dice = a.labels != nullptr;
@@ -494,9 +501,9 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
 template <int KH>
 int launch_dw(const ConvBwdWArgs& a, int ci_t, int co_t, hipStream_t s, const char* layer, double flops, double bytes) {
     dim3 grid(a.npb, cdiv(a.Cin, ci_t), cdiv(a.Cout, co_t)), block(kBlock);
-    char nm[48]; snprintf(nm, sizeof nm, "conv_bwd_w_k<%d,%d,%d>", KH, ci_t, co_t);
+    char nm[64]; snprintf(nm, sizeof nm, "conv_bwd_w_k<%d,%d,%d,%s>", KH, ci_t, co_t, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, layer, flops, bytes);
-#define DW_CASE(CI, CO) if (ci_t == CI && co_t == CO) { conv_bwd_w_k<KH, CI, CO><<<grid, block, 0, s>>>(a); HIP_OK(hipGetLastError()); return 0; }
+#define DW_CASE(CI, CO) if (ci_t == CI && co_t == CO) { AT_DISPATCH(a.act_bf16, conv_bwd_w_k<KH, CI, CO, AT><<<grid, block, 0, s>>>(a)); HIP_OK(hipGetLastError()); return 0; }
     DW_CASE(1, 4) DW_CASE(1, 8) DW_CASE(1, 16)
 #undef DW_CASE
     return fail(-3, "dW: unsupported channel chunking");
@@ -527,7 +534,7 @@ int flush_reduce(oct_unet* h, hipStream_t s) {
     return 0;
 }
 
-int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const float* dz, int B, hipStream_t s) {
+int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const void* dz, int B, hipStream_t s) {
     const Layer& l = h->plan.L[li];
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
     const DwPlan p = dw_plan(l, B);
@@ -537,25 +544,26 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const fl
     a.dz = dz; a.part = l.dwp;
     a.B = B; a.H = l.H; a.W = l.W; a.Cin = l.cin; a.Cout = l.cout;
     a.tiles_x = cdiv(l.W, kTileX); a.tiles = p.tiles; a.total_tiles = B * a.tiles; a.npb = p.npb;
-    a.drop = make_drop(h);
+    a.drop = make_drop(h); a.act_bf16 = h->cfg.dtype;
     const double px = (double)B * l.H * l.W, fl = 2.0 * l.kh * l.kw * l.cin * l.cout * px;
-    const double by = in_bytes(l, B, x_is_u8) + px * l.cout * 4;   // conv input once + dz once
+    const int es = h->cfg.dtype ? 2 : 4;
+    const double by = in_bytes(l, B, x_is_u8, es) + px * l.cout * es;   // conv input once + dz once
     const bool up = l.src == SRC_UP;
     int rc = 0;
     if (p.kind == 0) {
         rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by);   // 1-channel (or odd-channel) first layer
     } else {
         dim3 grid(p.npb, cdiv(l.cin, p.cic), cdiv(l.cout, p.coc)), block(kBlock);
-        char nm[48];
-        if (p.kind == 16) snprintf(nm, sizeof nm, "conv_dw16_k<%d,%d,%s>", l.kh, p.cic, up ? "true" : "false");
-        else snprintf(nm, sizeof nm, "conv_dw32_k<%d,%d,%s,%d>", l.kh, p.cic, up ? "true" : "false", p.th);
+        char nm[64];
+        if (p.kind == 16) snprintf(nm, sizeof nm, "conv_dw16_k<%d,%d,%s,%s>", l.kh, p.cic, up ? "true" : "false", AT_NAME(a.act_bf16));
+        else snprintf(nm, sizeof nm, "conv_dw32_k<%d,%d,%s,%d,%s>", l.kh, p.cic, up ? "true" : "false", p.th, AT_NAME(a.act_bf16));
         ProfScope ps(s, nm, l.name, fl, by);
         if (p.kind == 16) {
-            if (up) { if (p.cic == 16) conv_dw16_k<2, 16, true><<<grid, block, 0, s>>>(a); else conv_dw16_k<2, 8, true><<<grid, block, 0, s>>>(a); }
-            else { if (p.cic == 16) conv_dw16_k<3, 16, false><<<grid, block, 0, s>>>(a); else conv_dw16_k<3, 8, false><<<grid, block, 0, s>>>(a); }
+            if (up) { if (p.cic == 16) AT_DISPATCH(a.act_bf16, conv_dw16_k<2, 16, true, AT><<<grid, block, 0, s>>>(a)); else AT_DISPATCH(a.act_bf16, conv_dw16_k<2, 8, true, AT><<<grid, block, 0, s>>>(a)); }
+            else { if (p.cic == 16) AT_DISPATCH(a.act_bf16, conv_dw16_k<3, 16, false, AT><<<grid, block, 0, s>>>(a)); else AT_DISPATCH(a.act_bf16, conv_dw16_k<3, 8, false, AT><<<grid, block, 0, s>>>(a)); }
         } else {
-            if (up) { if (p.cic == 64) conv_dw32_k<2, 64, true, 2><<<grid, block, 0, s>>>(a); else conv_dw32_k<2, 32, true, 4><<<grid, block, 0, s>>>(a); }
-            else { if (p.cic == 64) conv_dw32_k<3, 64, false, 2><<<grid, block, 0, s>>>(a); else conv_dw32_k<3, 32, false, 4><<<grid, block, 0, s>>>(a); }
+            if (up) { if (p.cic == 64) AT_DISPATCH(a.act_bf16, conv_dw32_k<2, 64, true, 2, AT><<<grid, block, 0, s>>>(a)); else AT_DISPATCH(a.act_bf16, conv_dw32_k<2, 32, true, 4, AT><<<grid, block, 0, s>>>(a)); }
+            else { if (p.cic == 64) AT_DISPATCH(a.act_bf16, conv_dw32_k<3, 64, false, 2, AT><<<grid, block, 0, s>>>(a)); else AT_DISPATCH(a.act_bf16, conv_dw32_k<3, 32, false, 4, AT><<<grid, block, 0, s>>>(a)); }
         }
         HIP_OK(hipGetLastError());
     }
@@ -574,8 +582,9 @@ int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s) {
       bn_bwd_finalize_k<<<l.cout, kBlock, 0, s>>>(f); }
     const size_t n4 = (size_t)B * l.H * l.W * l.cout / 4;
     const int grid = (int)std::min<size_t>((n4 + kBlock - 1) / kBlock, 8192);
-    ProfScope ps(s, "bn_bwd_apply_k", l.name, 0, (double)n4 * 16 * 3);
-    bn_bwd_apply_k<<<grid, kBlock, 0, s>>>(l.g, l.z, l.bn, h->params + l.gamma_off, n4, l.cout);
+    const int bf = h->cfg.dtype;
+    ProfScope ps(s, bf ? "bn_bwd_apply_k<unsigned short>" : "bn_bwd_apply_k<float>", l.name, 0, (double)n4 * (bf ? 8 : 16) * 3);
+    AT_DISPATCH(bf, bn_bwd_apply_k<AT><<<grid, kBlock, 0, s>>>((AT*)l.g, (const AT*)l.z, l.bn, h->params + l.gamma_off, n4, l.cout));
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -588,7 +597,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     HeadBwdArgs hb{};
     hb.z = last.z; hb.bn = last.bn; hb.w = h->params + hd.w_off; hb.bias = h->params + hd.b_off;
     hb.labels = labels; hb.bc = h->dice_bc; hb.g = last.g; hb.part = h->stat_part; hb.wpart = hd.dwp;
-    hb.HW = hd.H * hd.W; hb.nblk = head_nblk(hb.HW, B); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale;
+    hb.HW = hd.H * hd.W; hb.nblk = head_nblk(hb.HW, B); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale; hb.act_bf16 = h->cfg.dtype;
     {   // backward-data weights of every block for this step's parameters (one launch)
         ProfScope ps(s, "prep_wt_k", "all", 0, (double)h->wt_total * 8);
         prep_wt_k<<<std::min<unsigned>((h->wt_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wt_descs, h->n_wt, h->wt_total);
@@ -610,16 +619,17 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         if (l.src == SRC_INPUT) break;
         // backward-data through the MFMA implicit-GEMM kernel: dz (plain) x transposed / effective weights
         int rows = 0;
-        auto dx = [&](float* gout, int Cg, int ci_off, const Layer* prod, bool up) -> int {
+        auto dx = [&](void* gout, int Cg, int ci_off, const Layer* prod, bool up) -> int {
             IgemmArgs g{};
             g.x0 = l.g; g.C0 = l.cout; g.flags = 0; g.Cin = l.cout;
             g.w = l.wt; g.w_ld = l.cin; g.m_off = ci_off; g.out = gout; g.Mout = Cg;
             g.Hi = l.H; g.Wi = l.W; g.Ho = up ? l.H / 2 : l.H; g.Wo = up ? l.W / 2 : l.W;
             g.part = prod ? h->stat_part : nullptr; g.zin = prod ? prod->z : nullptr; g.bnin = prod ? prod->bn : nullptr;
-            g.drop_out = (up && l.drop_in) ? 1 : 0; g.drop = make_drop(h);
+            g.drop_out = (up && l.drop_in) ? 1 : 0; g.drop = make_drop(h); g.act_bf16 = h->cfg.dtype;
             const double px = (double)B * l.H * l.W, pxg = (double)B * g.Ho * g.Wo;
             const double fl = 2.0 * l.kh * l.kw * Cg * l.cout * px;          // algorithmic flops of the original conv's dX
-            const double by = px * l.cout * 4 + pxg * Cg * 4 * (prod ? 2 : 1);
+            const int es = h->cfg.dtype ? 2 : 4;
+            const double by = px * l.cout * es + pxg * Cg * es * (prod ? 2 : 1);
             if (up) return launch_igemm<3, A_DOWN2, EPI_MASK>(g, B, s, l.name, fl, by, &rows);
             return prod ? launch_igemm<3, A_NORMAL, EPI_MASK>(g, B, s, l.name, fl, by, &rows)
                         : launch_igemm<3, A_NORMAL, EPI_RAW>(g, B, s, l.name, fl, by, &rows);
@@ -638,11 +648,12 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
                 if (rc) return rc;
                 PoolBwdArgs pb{};
                 pb.gp = h->gpooled[l.level - 1]; pb.z = p.z; pb.bn = p.bn; pb.g = p.g; pb.part = h->stat_part;
-                pb.H = p.H; pb.W = p.W; pb.C = p.cout; pb.tiles_x = cdiv(p.W / 2, kTileX); pb.tiles = tiles_of(p.H / 2, p.W / 2);
+                pb.act_bf16 = h->cfg.dtype; pb.H = p.H; pb.W = p.W; pb.C = p.cout; pb.tiles_x = cdiv(p.W / 2, kTileX); pb.tiles = tiles_of(p.H / 2, p.W / 2);
                 const int c_t = 4;
                 dim3 grid(pb.tiles, p.cout / c_t, B);
-                ProfScope ps(s, c_t == 8 ? "pool_bwd_k<8>" : "pool_bwd_k<4>", p.name, 0, (double)B * p.H * p.W * p.cout * 4 * 3.25);
-                if (c_t == 8) pool_bwd_k<8><<<grid, kBlock, 0, s>>>(pb); else pool_bwd_k<4><<<grid, kBlock, 0, s>>>(pb);
+                const int bf = h->cfg.dtype;
+                ProfScope ps(s, bf ? "pool_bwd_k<4,unsigned short>" : "pool_bwd_k<4,float>", p.name, 0, (double)B * p.H * p.W * p.cout * (bf ? 2 : 4) * 3.25);
+                AT_DISPATCH(bf, pool_bwd_k<4, AT><<<grid, kBlock, 0, s>>>(pb));
                 HIP_OK(hipGetLastError());
                 pending_nblk = B * pb.tiles;
                 break;
@@ -898,9 +909,10 @@ int oct_set_option(const char* name, int value) {
     return fail(-1, std::string("unknown option: ") + name);
 }
 
-const float* oct_unet_debug_activation(oct_unet* h, int layer, int which) {
+const void* oct_unet_debug_activation(oct_unet* h, int layer, int which) {
     if (!h || layer < 0 || layer >= (int)h->plan.L.size()) return nullptr;
-    return which == 0 ? h->plan.L[layer].z : h->plan.L[layer].g;
+    const Layer& l = h->plan.L[layer];
+    return which == 0 ? (const void*)l.z : which == 1 ? (const void*)l.g : which == 2 ? (const void*)l.bn : nullptr;
 }
 
 }  // extern "C"

@@ -33,7 +33,7 @@ def make_cfg(*, input_channels: int, num_classes: int, image_height: int, image_
              enc_kernel: Sequence[int] = (3, 3), dec_kernel: Sequence[int] = (2, 2),
              max_batch: int = 1, training: bool = False, seed: int = 0,
              bn_eps: float = 1e-3, bn_momentum: float = 0.99, dropout_rate: float = 0.5,
-             bn_unbiased_moving_var: bool = True) -> UNetCfg:
+             bn_unbiased_moving_var: bool = True, dtype="float32") -> UNetCfg:
     ek, dk = tuple(enc_kernel), tuple(dec_kernel)
     if ek[0] != ek[1] or dk[0] != dk[1]:
         raise OctError("only square kernels are supported")
@@ -41,7 +41,10 @@ def make_cfg(*, input_channels: int, num_classes: int, image_height: int, image_
     _hip.lib().oct_unet_cfg_default(C.byref(cfg))
     cfg.in_ch, cfg.n_cls, cfg.H, cfg.W = input_channels, num_classes, image_height, image_width
     cfg.max_batch, cfg.start_neurons, cfg.pool_layers, cfg.conv_layers = max_batch, start_neurons, pool_layers, conv_layers
-    cfg.enc_k, cfg.dec_k, cfg.dtype, cfg.training = ek[0], dk[0], 0, int(training)
+    dmap = {"float32": 0, "f32": 0, 0: 0, "bfloat16": 1, "bf16": 1, 1: 1}
+    if dtype not in dmap:
+        raise OctError(f"dtype must be 'float32' or 'bfloat16' (activation storage), got {dtype!r}")
+    cfg.enc_k, cfg.dec_k, cfg.dtype, cfg.training = ek[0], dk[0], dmap[dtype], int(training)
     cfg.bn_eps, cfg.bn_momentum, cfg.dropout_rate = bn_eps, bn_momentum, dropout_rate
     cfg.bn_unbiased_moving_var, cfg.seed = int(bn_unbiased_moving_var), seed & 0xFFFFFFFFFFFFFFFF
     _hip.check(_hip.lib().oct_unet_cfg_check(C.byref(cfg)), "oct_unet_cfg_check")
@@ -286,12 +289,25 @@ class UNetEngine:
             raise OctError("set_weights: too many arrays")
         self.params.copy_(torch.from_numpy(p)); self.state.copy_(torch.from_numpy(s))
 
+    def debug_bn_record(self, layer: int) -> torch.Tensor:
+        """The (6, cout) f32 BN record the consumers of ``layer`` apply on load: rows a, b, mean, rstd, c1, c2."""
+        ptr = _hip.lib().oct_unet_debug_activation(self._h, layer, 2)
+        if not ptr:
+            raise OctError("no BN record for this layer")
+        c = self.layers[layer]["cout"]
+        off = ptr - self.workspace.data_ptr()
+        return self.workspace[off:off + 4 * 6 * c].view(torch.float32).view(6, c)
+
     def debug_activation(self, layer: int, which: int = 0) -> torch.Tensor:
-        """View of a layer's saved pre-BN output (which=0) or gradient buffer (which=1), max_batch-sized."""
+        """A layer's saved pre-BN output (which=0) or gradient buffer (which=1), max_batch-sized; a float32 view in
+        f32 mode, a float32 COPY of the bf16 storage in bf16 mode."""
         ptr = _hip.lib().oct_unet_debug_activation(self._h, layer, which)
         if not ptr:
             raise OctError("no such activation")
         L = self.layers[layer]
         n = self.cfg.max_batch * L["out_h"] * L["out_w"] * L["cout"]
         off = ptr - self.workspace.data_ptr()
-        return self.workspace[off:off + 4 * n].view(torch.float32).view(self.cfg.max_batch, L["out_h"], L["out_w"], L["cout"])
+        shape = (self.cfg.max_batch, L["out_h"], L["out_w"], L["cout"])
+        if self.cfg.dtype == 1:
+            return self.workspace[off:off + 2 * n].view(torch.bfloat16).view(shape).float()
+        return self.workspace[off:off + 4 * n].view(torch.float32).view(shape)

@@ -140,7 +140,8 @@ class Model:
             dec_kernel=tuple(c.get("dec_kernel", (2, 2))),
             max_batch=max(batch, e.cfg.max_batch if e is not None else 1),
             training=training or (e is not None and bool(e.cfg.training)),
-            seed=int(c.get("seed", 0)) * 1000003 + rank, init_seed=int(c.get("seed", 0)))
+            seed=int(c.get("seed", 0)) * 1000003 + rank, init_seed=int(c.get("seed", 0)),
+            dtype=c.get("dtype", "float32"))   # extension key: 'bfloat16' = bf16 activation storage (BASELINE configs[2])
         if weights is not None:
             self._engine.set_weights(weights)
         if opt_state is not None:
