@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--infer-batch", type=int, default=128)
+    ap.add_argument("--act-dtype", choices=["f32", "bf16"], default="f32",
+                    help="activation STORAGE type (arithmetic is f32 either way); the headline metric is f32")
+    ap.add_argument("--pool-layers", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dump-profile", default=None, help="write the per-(kernel, layer) launch table to this JSON file")
@@ -104,7 +107,8 @@ def main():
     B, H, W, C = args.batch, args.height, args.width, args.classes
 
     eng = UNetEngine(device=dev, input_channels=1, num_classes=C, image_height=H, image_width=W,
-                     max_batch=max(B, args.infer_batch), training=True, seed=1000 + rank, init_seed=0)
+                     max_batch=max(B, args.infer_batch), training=True, seed=1000 + rank, init_seed=0,
+                     pool_layers=args.pool_layers, dtype={"f32": "float32", "bf16": "bfloat16"}[args.act_dtype])
     parallel.broadcast_parameters(eng.params, eng.state)
     # a few distinct synthetic scans per rank, tiled to the batch (host generation is not part of the step)
     nd = min(B, 8)
@@ -150,9 +154,10 @@ def main():
         "metric": "B-scans/sec (train step), 256x512 3-class U-Net", "value": round(scans_per_s, 2),
         "unit": "B-scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.act_dtype == "f32" else "f32 math / bf16 activation storage",
+        "data": "synthetic",
         "config": {"workload": f"configs[1]: train step (fwd+Dice-macro+bwd+allreduce+Adam), per-GPU batch {B}, "
-                               f"{H}x{W}x1, {C}-class, pool_layers=4, start_neurons=8, random-init weights",
+                               f"{H}x{W}x1, {C}-class, pool_layers={args.pool_layers}, start_neurons=8, random-init weights",
                    "global_batch": B * world, "parallelism": f"dp{world}"},
         "inference_ms_per_scan": round(infer_ms, 5), "inference_batch": IB, "final_loss": round(final_loss, 5),
     }

@@ -123,7 +123,7 @@ int oct_unet_graph_launch(oct_unet* h, oct_stream_t stream);
  * end() synchronises the device and returns one entry per (kernel instantiation, layer) with the summed
  * duration and the ALGORITHMIC flops/bytes of those launches (cost model). */
 typedef struct oct_profile_entry {
-    char kernel[48];
+    char kernel[80];
     char layer[32];
     int launches;
     double total_ms, flops, bytes;

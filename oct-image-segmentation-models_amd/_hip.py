@@ -38,7 +38,7 @@ class LayerInfo(C.Structure):
 
 
 class ProfileEntry(C.Structure):
-    _fields_ = [("kernel", C.c_char * 48), ("layer", C.c_char * 32), ("launches", C.c_int),
+    _fields_ = [("kernel", C.c_char * 80), ("layer", C.c_char * 32), ("launches", C.c_int),
                 ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 

@@ -27,14 +27,14 @@ def short(name):
     return name.replace("void oct::", "").replace("oct::", "").split("(")[0].replace(", ", ",")
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)   # newest run
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 for f in ("bench.json", "launch_table.json"):
     shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
 
 traffic = collections.defaultdict(lambda: dict(launches=0, fetch_kb=0.0, write_kb=0.0))
 for counter, key in (("FETCH_SIZE", "fetch_kb"), ("WRITE_SIZE", "write_kb")):
-    f = glob.glob(os.path.join(src, f"pmc_{counter}", "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, f"pmc_{counter}", "*", "*_counter_collection.csv")), key=os.path.getmtime)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter or "oct::" not in r["Kernel_Name"]:
             continue
