@@ -15,6 +15,7 @@
 #include "kernels_igemm.hpp"
 #include "kernels_dw.hpp"
 #include "kernels_thin.hpp"
+#include "kernels_pair.hpp"
 
 using namespace oct;
 
@@ -22,6 +23,7 @@ namespace {
 
 thread_local std::string g_err;
 int g_thin_min_tiles = 2048;      // pixel tiles from which 8-channel layers use the VALU thin kernel
+int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
 int g_persist_min_tiles = 2048;   // pixel tiles from which thin single-chunk convs use the persistent pipelined kernel
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -311,6 +313,34 @@ int launch_igemm_p(IgemmArgs a, int B, hipStream_t s, const char* layer, double 
     return 0;
 }
 
+// resident blocks per CU of a kernel (queried once per instantiation) -> grid of a persistent launch
+template <typename K>
+int resident_blocks(K kern, int fallback) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kBlock, 0) != hipSuccess || nb < 1) nb = fallback;
+    return nb;
+}
+
+// pixel-pair MFMA kernel for 3x3 layers with 8 output channels (see kernels_pair.hpp)
+template <int EPI>
+int launch_pair8(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+    a.tiles_x = cdiv(a.Wo, 64); a.tiles = a.tiles_x * cdiv(a.Ho, 8); a.total_tiles = B * a.tiles;
+    static int occ[2][2] = {{0, 0}, {0, 0}};
+    const int wide = a.Cin <= 8 ? 0 : 1, bf = a.act_bf16 ? 1 : 0;
+    if (!occ[wide][bf]) {
+        if (wide) AT_DISPATCH(bf, occ[wide][bf] = resident_blocks(conv_pair8_k<EPI, 16, AT>, 3));
+        else AT_DISPATCH(bf, occ[wide][bf] = resident_blocks(conv_pair8_k<EPI, 8, AT>, 4));
+    }
+    const int nblk = std::min(a.total_tiles, occ[wide][bf] * 256);
+    char nm[64]; snprintf(nm, sizeof nm, "conv_pair8_k<%d,%d,%s>", EPI, wide ? 16 : 8, AT_NAME(a.act_bf16));
+    ProfScope ps(s, nm, layer, flops, bytes);
+    if (!wide) AT_DISPATCH(bf, conv_pair8_k<EPI, 8, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
+    else AT_DISPATCH(bf, conv_pair8_k<EPI, 16, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
+    HIP_OK(hipGetLastError());
+    *rows = nblk;
+    return 0;
+}
+
 // VALU kernel for 8-output-channel layers (see kernels_thin.hpp)
 template <int KH, int AMODE, int EPI>
 int launch_thin8(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
@@ -328,6 +358,11 @@ int launch_thin8(IgemmArgs a, int B, hipStream_t s, const char* layer, double fl
 template <int KH, int AMODE, int EPI>
 int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
     auto blocks = [&](int th, int mb) { return (long)B * cdiv(a.Ho, th) * cdiv(a.Wo, 32) * cdiv(a.Mout, mb); };
+    if constexpr (AMODE == A_NORMAL && KH == 3) {
+        // 8 output channels, 3x3: two adjacent pixels share one 16-row MFMA tile (75 % useful instead of 50 %)
+        if (a.Mout == 8 && a.Cin <= 16 && blocks(8, 16) >= g_pair_min_tiles)
+            return launch_pair8<EPI>(a, B, s, layer, flops, bytes, rows);
+    }
     if constexpr (AMODE != A_DOWN2) {
         // 8 output channels: a 16-row MFMA tile would be half padding -> VALU kernel (same f32 peak, no padding)
         if (a.Mout == 8 && a.Cin <= 16 && blocks(8, 16) >= g_thin_min_tiles)
@@ -905,6 +940,7 @@ int oct_boundary_maps(const unsigned char* labels, int B, int H, int W, int n_cl
 int oct_set_option(const char* name, int value) {
     if (!name) return fail(-1, "null option name");
     if (!strcmp(name, "igemm_persistent_min_tiles")) { g_persist_min_tiles = value < 1 ? 1 : value; return 0; }
+    if (!strcmp(name, "pair8_min_tiles")) { g_pair_min_tiles = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "thin8_min_tiles")) { g_thin_min_tiles = value < 1 ? 1 : value; return 0; }
     return fail(-1, std::string("unknown option: ") + name);
 }
