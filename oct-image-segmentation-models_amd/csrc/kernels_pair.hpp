@@ -24,7 +24,7 @@
 namespace oct {
 
 // grid (nblk, 1, 1); requires KH == 3, A_NORMAL, Mout == 8, Cin <= CMAX (Cin % 4 == 0)
-template <int EPI, int CMAX, typename AT>
+template <int EPI, int CMAX, int DEPTH, typename AT>
 __global__ __launch_bounds__(kBlock) void conv_pair8_k(const IgemmArgs A, const float* __restrict__ wgt, AT* __restrict__ outp) {
     constexpr int TH = 8, TW = 64, M = 8;
     constexpr int IH = TH + 2, IW = TW + 2, IWP = IW;
@@ -68,17 +68,9 @@ __global__ __launch_bounds__(kBlock) void conv_pair8_k(const IgemmArgs A, const 
 
     const float* const bbase = Is + g * PLANE + ry0 * IWP + cx0 + 2 * n;
 
-    TileOrg cur = walk.first(A.tiles);
-    if (walk.tl0 < walk.tlend) st.load(A, cur);
-    for (int tl = walk.tl0; tl < walk.tlend; tl += walk.step) {
-        __syncthreads();                    // every wave has finished reading the previous tile image
-        st.store(A, cur);
-        __syncthreads();
-        const TileOrg nxt = walk.next(cur);
-        if (tl + walk.step < walk.tlend) st.load(A, nxt);
-        const int b = cur.b, y0 = cur.ty * TH + ry0, x = cur.tx * TW + cx0 + 2 * n + pj;
-        cur = nxt;
-
+    // one tile: MFMA sweep over the LDS image + epilogue
+    auto process = [&](const TileOrg& o) {
+        const int b = o.b, y0 = o.ty * TH + ry0, x = o.tx * TW + cx0 + 2 * n + pj;
         float4 zq[4];
         if constexpr (EPI == EPI_MASK) {    // producer's z for the ReLU mask: in flight during the MFMA loop
 #pragma unroll
@@ -132,6 +124,33 @@ __global__ __launch_bounds__(kBlock) void conv_pair8_k(const IgemmArgs A, const 
             }
             if (valid) sta4<AT>(outp + pix * M + ch0, make_float4(v[0], v[1], v[2], v[3]));
         }
+    };
+
+    // software pipeline over the block's tiles: while tile t is computed from LDS, tile t+1 waits in one register
+    // buffer and (DEPTH 2) the loads of tile t+2 are in flight into the other -- the loop is unrolled by two so both
+    // buffers are statically indexed
+    typename decltype(st)::Buf pf0, pf1;
+    const int stp = walk.step, end = walk.tlend;
+    TileOrg o0 = walk.first(A.tiles), o1 = walk.next(o0);
+    if (walk.tl0 < end) st.load(A, o0, pf0);
+    if constexpr (DEPTH == 2) { if (walk.tl0 + stp < end) st.load(A, o1, pf1); }
+    for (int tl = walk.tl0; tl < end; tl += 2 * stp) {
+        __syncthreads();                    // every wave has finished reading the previous tile image
+        st.store(A, o0, pf0);
+        __syncthreads();
+        const TileOrg o2 = walk.next(o1);
+        if constexpr (DEPTH == 2) { if (tl + 2 * stp < end) st.load(A, o2, pf0); }
+        else { if (tl + stp < end) st.load(A, o1, pf1); }
+        process(o0);
+        if (tl + stp >= end) break;
+        __syncthreads();
+        st.store(A, o1, pf1);
+        __syncthreads();
+        const TileOrg o3 = walk.next(o2);
+        if constexpr (DEPTH == 2) { if (tl + 3 * stp < end) st.load(A, o3, pf1); }
+        else { if (tl + 2 * stp < end) st.load(A, o2, pf0); }
+        process(o1);
+        o0 = o2; o1 = o3;
     }
     if constexpr (EPI != EPI_RAW) {
         if (A.part) {

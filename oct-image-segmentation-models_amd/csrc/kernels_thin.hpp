@@ -55,7 +55,8 @@ struct ThinStager {
     static constexpr int Q = CMAX / 4, PPI = kBlock / Q, NPIX = IH * IW, NPF = (NPIX + PPI - 1) / PPI;
     const AT* __restrict__ src; float* lds_q;
     int Csrc, cc; bool cok;
-    float4 fa, fb, pf[NPF];
+    float4 fa, fb;
+    struct Buf { float4 v[NPF]; };     // one tile's worth of prefetched registers
     int lxy[NPF];
 
     __device__ __forceinline__ void init(const IgemmArgs& A, float* Is) {
@@ -78,7 +79,7 @@ struct ThinStager {
         iy0 = AMODE == A_NORMAL ? y0 - 1 : y0 / 2; ix0 = AMODE == A_NORMAL ? x0 - 1 : x0 / 2;
     }
     // issue the global loads of tile o (out-of-image / absent channels load nothing and become zeros)
-    __device__ __forceinline__ void load(const IgemmArgs& A, const TileOrg& o) {
+    __device__ __forceinline__ void load(const IgemmArgs& A, const TileOrg& o, Buf& pf) {
         int iy0, ix0; origin(o, iy0, ix0);
         const long long basepix = ((long long)o.b * A.Hi + iy0) * A.Wi + ix0;       // wave-uniform (may point into the halo)
         const AT* __restrict__ tb = src + basepix * Csrc;
@@ -88,11 +89,11 @@ struct ThinStager {
             const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
             bool ok = cok && lxy[k] >= 0;
             if (!interior) ok = ok && (unsigned)(iy0 + ly) < (unsigned)A.Hi && (unsigned)(ix0 + lx) < (unsigned)A.Wi;
-            pf[k] = ok ? lda4<AT>(tb + (ly * A.Wi + lx) * Csrc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pf.v[k] = ok ? lda4<AT>(tb + (ly * A.Wi + lx) * Csrc) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     // write the prefetched tile to LDS with the transform applied
-    __device__ __forceinline__ void store(const IgemmArgs& A, const TileOrg& o) {
+    __device__ __forceinline__ void store(const IgemmArgs& A, const TileOrg& o, const Buf& pf) {
         int iy0, ix0; origin(o, iy0, ix0);
         const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= A.Hi && ix0 + IW <= A.Wi;
         const int basepix = (o.b * A.Hi + iy0) * A.Wi + ix0;                      // only used for the dropout element index
@@ -100,7 +101,7 @@ struct ThinStager {
         for (int k = 0; k < NPF; ++k) {
             if (lxy[k] < 0) continue;
             const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
-            float4 v = pf[k];
+            float4 v = pf.v[k];
             bool in = cok;
             if (!interior) in = in && (unsigned)(iy0 + ly) < (unsigned)A.Hi && (unsigned)(ix0 + lx) < (unsigned)A.Wi;
             if (A.flags & F_AFF) {       // zero padding is applied AFTER the activation: out-of-image stays 0
@@ -144,13 +145,14 @@ __global__ __launch_bounds__(kBlock) void conv_thin8_k(const IgemmArgs A, const 
     for (int m = 0; m < M; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
 
     TileOrg cur = walk.first(A.tiles);
-    if (walk.tl0 < walk.tlend) st.load(A, cur);
+    typename decltype(st)::Buf pf;
+    if (walk.tl0 < walk.tlend) st.load(A, cur, pf);
     for (int tl = walk.tl0; tl < walk.tlend; tl += walk.step) {
         __syncthreads();                    // every wave has finished reading the previous tile image
-        st.store(A, cur);
+        st.store(A, cur, pf);
         __syncthreads();
         const TileOrg nxt = walk.next(cur);
-        if (tl + walk.step < walk.tlend) st.load(A, nxt);
+        if (tl + walk.step < walk.tlend) st.load(A, nxt, pf);
         const int b = cur.b, y0 = cur.ty * TH, x0 = cur.tx * TW;
         cur = nxt;
         const int y = y0 + ty, x = x0 + 2 * tx;

@@ -321,6 +321,9 @@ int resident_blocks(K kern, int fallback) {
     return nb;
 }
 
+#ifndef PAIR_DEPTH
+#define PAIR_DEPTH 1     // register prefetch depth of the 8-input-channel pair kernel (tiles in flight beyond the one in LDS)
+#endif
 // pixel-pair MFMA kernel for 3x3 layers with 8 output channels (see kernels_pair.hpp)
 template <int EPI>
 int launch_pair8(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
@@ -328,14 +331,14 @@ int launch_pair8(IgemmArgs a, int B, hipStream_t s, const char* layer, double fl
     static int occ[2][2] = {{0, 0}, {0, 0}};
     const int wide = a.Cin <= 8 ? 0 : 1, bf = a.act_bf16 ? 1 : 0;
     if (!occ[wide][bf]) {
-        if (wide) AT_DISPATCH(bf, occ[wide][bf] = resident_blocks(conv_pair8_k<EPI, 16, AT>, 3));
-        else AT_DISPATCH(bf, occ[wide][bf] = resident_blocks(conv_pair8_k<EPI, 8, AT>, 4));
+        if (wide) AT_DISPATCH(bf, occ[wide][bf] = resident_blocks(conv_pair8_k<EPI, 16, 1, AT>, 3));
+        else AT_DISPATCH(bf, occ[wide][bf] = resident_blocks(conv_pair8_k<EPI, 8, PAIR_DEPTH, AT>, 4));
     }
     const int nblk = std::min(a.total_tiles, occ[wide][bf] * 256);
-    char nm[64]; snprintf(nm, sizeof nm, "conv_pair8_k<%d,%d,%s>", EPI, wide ? 16 : 8, AT_NAME(a.act_bf16));
+    char nm[64]; snprintf(nm, sizeof nm, "conv_pair8_k<%d,%d,%d,%s>", EPI, wide ? 16 : 8, wide ? 1 : PAIR_DEPTH, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, layer, flops, bytes);
-    if (!wide) AT_DISPATCH(bf, conv_pair8_k<EPI, 8, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
-    else AT_DISPATCH(bf, conv_pair8_k<EPI, 16, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
+    if (!wide) AT_DISPATCH(bf, conv_pair8_k<EPI, 8, PAIR_DEPTH, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
+    else AT_DISPATCH(bf, conv_pair8_k<EPI, 16, 1, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
     HIP_OK(hipGetLastError());
     *rows = nblk;
     return 0;
