@@ -98,6 +98,11 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        # tuning knobs for experiments: OCT_OPTIONS="name=value,name=value" (oct_set_option; results do not depend on them)
+        for kv in filter(None, os.environ.get("OCT_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            if l.oct_set_option(k.strip().encode(), int(v)) != 0:
+                raise OctError(f"OCT_OPTIONS: {l.oct_last_error().decode()}")
     return _lib
 
 

@@ -89,6 +89,40 @@ __host__ __device__ inline int chan_of_lane(int lane) {
     return c;
 }
 
+// ---- column sums of a [rows][2*C] partial table for channel c, in fp64, by one block of kBlock threads ----
+// The loads of 8 rows are issued together (independent, so one memory round trip covers 8 rows per thread instead of a
+// dependent chain), the block sum is a wave shuffle tree + one LDS step.  Fixed summation order: deterministic.
+// Returns the two sums in every thread of wave 0 (use thread 0).  `sh` = 8 doubles of LDS.
+__device__ inline void column_sums_f64(const float* __restrict__ part, int rows, int C, int c, double* sh, double& s, double& q) {
+    s = 0; q = 0;
+    const size_t ld = 2 * (size_t)C;
+    int i = threadIdx.x;
+    for (; i + 7 * kBlock < rows; i += 8 * kBlock) {
+        float a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float* r = part + (size_t)(i + k * kBlock) * ld + c; a[k] = r[0]; b[k] = r[C]; }
+        s += (((double)a[0] + a[1]) + ((double)a[2] + a[3])) + (((double)a[4] + a[5]) + ((double)a[6] + a[7]));
+        q += (((double)b[0] + b[1]) + ((double)b[2] + b[3])) + (((double)b[4] + b[5]) + ((double)b[6] + b[7]));
+    }
+    {   // tail: up to 7 rows per thread, still issued together
+        float a[7], b[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int r_ = i + k * kBlock; const bool ok = r_ < rows;
+            const float* r = part + (size_t)(ok ? r_ : 0) * ld + c;
+            a[k] = ok ? r[0] : 0.f; b[k] = ok ? r[C] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { s += a[k]; q += b[k]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[wave] = s; sh[4 + wave] = q; }
+    __syncthreads();
+    s = (sh[0] + sh[1]) + (sh[2] + sh[3]); q = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+}
+
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ inline void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 

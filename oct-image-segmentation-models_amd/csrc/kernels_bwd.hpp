@@ -89,24 +89,15 @@ struct BnBwdFinArgs {
 };
 
 __global__ __launch_bounds__(kBlock) void bn_bwd_finalize_k(const BnBwdFinArgs A) {
-    __shared__ double sh[2][kBlock];
+    __shared__ double sh[8];
     const int c = blockIdx.x;
-    double s = 0, q = 0;
-    for (int i = threadIdx.x; i < A.nblk; i += kBlock) {
-        s += A.part[(size_t)i * 2 * A.C + c];
-        q += A.part[(size_t)i * 2 * A.C + A.C + c];
-    }
-    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
-    __syncthreads();
-    for (int o = kBlock / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
-        __syncthreads();
-    }
+    double s, q;
+    column_sums_f64(A.part, A.nblk, A.C, c, sh, s, q);
     if (threadIdx.x == 0) {
-        A.dbeta[c] = (float)sh[0][0];
-        A.dgamma[c] = (float)sh[1][0];
-        A.bn[BN_C1 * A.C + c] = (float)(sh[0][0] / A.count);
-        A.bn[BN_C2 * A.C + c] = (float)(sh[1][0] / A.count);
+        A.dbeta[c] = (float)s;
+        A.dgamma[c] = (float)q;
+        A.bn[BN_C1 * A.C + c] = (float)(s / A.count);
+        A.bn[BN_C2 * A.C + c] = (float)(q / A.count);
     }
 }
 
@@ -298,6 +289,63 @@ __global__ __launch_bounds__(kBlock) void conv_bwd_w_k(const ConvBwdWArgs A) {
             else if (ci0 + ci == 0) out[wsize + co0 + co] = s;   // bias gradient = sum dz
         }
     }
+}
+
+// ---- first layer, the real configuration (1 input channel, 8 output channels, 3x3): dW[tap][co] = sum_px x(px+tap) dz(px)[co]
+// Pure streaming reduction over dz (32 B/pixel, read straight from global memory, fully coalesced) against the image tile
+// in LDS; every thread keeps all 72 weight + 8 bias sums in registers, one block reduction per persistent block.
+// grid (npb); partial slab layout [tap][co] (72) + bias (8) = the generic [tap][ci][co] + bias layout for Cin = 1.
+template <typename AT>
+__global__ __launch_bounds__(kBlock) void conv_dw_first_k(const ConvBwdWArgs A, int tiles_x, int tiles, int total_tiles) {
+    constexpr int TH = 8, TW = 128, XH = TH + 2, XW = TW + 2;
+    __shared__ float Xs[XH * XW];
+    __shared__ float red[256];
+    const int t = threadIdx.x, xl = t & 31, row = t >> 5;
+    float acc0[64], acc1[16];       // acc0 = taps 0..7 x 8 channels; acc1 = tap 8 x 8 channels, then the 8 bias sums
+#pragma unroll
+    for (int k = 0; k < 64; ++k) acc0[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc1[k] = 0.f;
+    const bool u8 = (A.flags & F_U8) != 0;
+    for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+        const int b = tl / tiles, tile = tl % tiles;
+        const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+        __syncthreads();
+        for (int i = t; i < XH * XW; i += kBlock) {
+            const int cy = i / XW, cx = i % XW, iy = y0 + cy - 1, ix = x0 + cx - 1;
+            float v = 0.f;
+            if (iy >= 0 && iy < A.H && ix >= 0 && ix < A.W) {
+                const size_t pix = ((size_t)b * A.H + iy) * A.W + ix;
+                v = u8 ? c_u8_lut[reinterpret_cast<const unsigned char*>(A.x0)[pix]] : reinterpret_cast<const float*>(A.x0)[pix];
+            }
+            Xs[i] = v;
+        }
+        __syncthreads();
+        const int y = y0 + row;
+#pragma unroll
+        for (int k = 0; k < TW / 32; ++k) {
+            const int xx = xl + 32 * k, x = x0 + xx;
+            if (y < A.H && x < A.W) {
+                const AT* dp = reinterpret_cast<const AT*>(A.dz) + (((size_t)b * A.H + y) * A.W + x) * 8;
+                const float4 d0 = lda4<AT>(dp), d1 = lda4<AT>(dp + 4);
+                const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float xv = Xs[(row + tap / 3) * XW + xx + tap % 3];
+#pragma unroll
+                    for (int co = 0; co < 8; ++co) {
+                        if (tap < 8) acc0[tap * 8 + co] = fmaf(xv, d[co], acc0[tap * 8 + co]);
+                        else acc1[co] = fmaf(xv, d[co], acc1[co]);
+                    }
+                }
+#pragma unroll
+                for (int co = 0; co < 8; ++co) acc1[8 + co] += d[co];
+            }
+        }
+    }
+    float* out = A.part + (size_t)blockIdx.x * 80;
+    block_reduce_store<64>(acc0, red, out, 64);
+    block_reduce_store<16>(acc1, red, out + 64, 16);
 }
 
 // second stage: grads[j] = sum over pixel blocks of part[pb][j].  Block = JW consecutive j x (256/JW) slices of

@@ -131,22 +131,13 @@ struct BnFinArgs {
 };
 
 __global__ __launch_bounds__(kBlock) void bn_fwd_finalize_k(const BnFinArgs A) {
-    __shared__ double sh[2][kBlock];
+    __shared__ double sh[8];
     const int c = blockIdx.x;
-    double s = 0, q = 0;
-    for (int i = threadIdx.x; i < A.nblk; i += kBlock) {
-        s += A.part[(size_t)i * 2 * A.C + c];
-        q += A.part[(size_t)i * 2 * A.C + A.C + c];
-    }
-    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
-    __syncthreads();
-    for (int o = kBlock / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
-        __syncthreads();
-    }
+    double s, q;
+    column_sums_f64(A.part, A.nblk, A.C, c, sh, s, q);
     if (threadIdx.x == 0) {
-        const double mean = sh[0][0] / A.count;
-        double var = sh[1][0] / A.count - mean * mean;
+        const double mean = s / A.count;
+        double var = q / A.count - mean * mean;
         if (var < 0) var = 0;
         const double rstd = 1.0 / sqrt(var + (double)A.eps);
         const double a = (double)A.gamma[c] * rstd;

@@ -8,8 +8,12 @@
 // 9 of the 12 window positions of every row carry a weight: 75 % of the MFMA is useful work (50 % for the padded
 // tile), which puts the MFMA time of an 8->8 layer at the HBM time of its tensors, and the staging / epilogue VALU
 // work runs beside the matrix pipe instead of competing with the FMAs for the vector ALU.
-//   * block = 4 waves, tile 8 rows x 64 cols; wave w owns rows 4*(w>>1)..+3, cols 32*(w&1)..+31 (4 accumulators:
-//     4 output rows share the A operand and, through the 3 kernel rows, their B operands);
+//   * a wave owns RPW groups of 4 output rows x 32 columns (4 accumulators per group: the 4 rows share the A operand
+//     and, through the 3 kernel rows, their B operands); a block is NWY x NWX waves on a (4 RPW NWY) x (32 NWX) tile.
+//     Measured (8->8 forward, B=32, 256x512): 2x2 waves x 1 group (8x64 tile) 83 us; 2x1 88; 1x1 (no cross-wave
+//     barrier at all) 100; 2x2 x 2 groups (16x64) 91; forcing 4 waves/SIMD (spills) 101.  Knock-outs: without the MFMA
+//     sweep 50 us (5.4 TB/s), without global loads/stores 89 us -- the LDS/MFMA/epilogue chain of a wave, not memory,
+//     is what bounds it (MFMA pipe 55 % busy at 3 waves/SIMD);
 //   * A operand (the weight matrix with its structural zeros) is built ONCE per persistent block in LDS, in lane
 //     order: one conflict-free ds_read_b32 serves the 4 MFMAs (4 output rows) of a K-step;
 //   * B operand: one ds_read_b32 per (window column, channel quad, input row) from the PLANAR LDS tile [c][row][col];
@@ -23,29 +27,29 @@
 
 namespace oct {
 
-// grid (nblk, 1, 1); requires KH == 3, A_NORMAL, Mout == 8, Cin <= CMAX (Cin % 4 == 0)
-template <int EPI, int CMAX, int DEPTH, typename AT>
-__global__ __launch_bounds__(kBlock) void conv_pair8_k(const IgemmArgs A, const float* __restrict__ wgt, AT* __restrict__ outp) {
-    constexpr int TH = 8, TW = 64, M = 8;
+// grid (nblk, 1, 1), block 64*NWY*NWX; requires KH == 3, A_NORMAL, Mout == 8, Cin <= CMAX (Cin % 4 == 0)
+template <int EPI, int CMAX, int DEPTH, int NWY, int NWX, int RPW, typename AT>
+__global__ __launch_bounds__(64 * NWY * NWX) void conv_pair8_k(const IgemmArgs A, const float* __restrict__ wgt, AT* __restrict__ outp) {
+    constexpr int TH = 4 * RPW * NWY, TW = 32 * NWX, M = 8, NW = NWY * NWX, NT = 64 * NW;
     constexpr int IH = TH + 2, IW = TW + 2, IWP = IW;
     constexpr int PLANE = (IH * IWP) | 1;
     constexpr int Q = CMAX / 4, NSTEP = 3 * 4 * Q;
     __shared__ float Is[CMAX * PLANE];
     __shared__ float Aw[NSTEP * 64];
-    __shared__ float red[4 * 16];
+    __shared__ float red[NW * 16];
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ry0 = 4 * (wave >> 1), cx0 = 32 * (wave & 1);
+    const int ry0 = 4 * RPW * (wave / NWX), cx0 = 32 * (wave % NWX);
     const int ch0 = 4 * (g & 1), pj = g >> 1;                  // this lane's output: channels ch0..ch0+3 of pixel 2n + pj
 
-    ThinStager<CMAX, IH, IW, IWP, PLANE, A_NORMAL, TH, TW, AT> st;
+    ThinStager<CMAX, IH, IW, IWP, PLANE, A_NORMAL, TH, TW, AT, NT> st;
     st.init(A, Is);
     TileWalk<TH, TW> walk;
     walk.init(A.tiles, A.tiles_x, A.total_tiles);
 
     // A operand: row (j, co) = n, k = g within the step (ky, u, q); identical for the 4 waves -> wave 0..3 build a quarter each
-    for (int e = tid; e < NSTEP * 64; e += kBlock) {
+    for (int e = tid; e < NSTEP * 64; e += NT) {
         const int sidx = e >> 6, ln = e & 63, nn = ln & 15, gg = ln >> 4;
         const int q = sidx % Q, u = (sidx / Q) & 3, ky = sidx / (4 * Q);
         const int kx = u - (nn >> 3), ci = 4 * q + gg;
@@ -70,7 +74,10 @@ __global__ __launch_bounds__(kBlock) void conv_pair8_k(const IgemmArgs A, const 
 
     // one tile: MFMA sweep over the LDS image + epilogue
     auto process = [&](const TileOrg& o) {
-        const int b = o.b, y0 = o.ty * TH + ry0, x = o.tx * TW + cx0 + 2 * n + pj;
+#pragma unroll 1
+      for (int rg = 0; rg < RPW; ++rg) {
+        const int b = o.b, y0 = o.ty * TH + ry0 + 4 * rg, x = o.tx * TW + cx0 + 2 * n + pj;
+        const float* const bb = bbase + 4 * rg * IWP;
         float4 zq[4];
         if constexpr (EPI == EPI_MASK) {    // producer's z for the ReLU mask: in flight during the MFMA loop
 #pragma unroll
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void conv_pair8_k(const IgemmArgs A, const 
             for (int q = 0; q < Q; ++q) {
                 float xin[6], aw[3];
 #pragma unroll
-                for (int t = 0; t < 6; ++t) xin[t] = bbase[4 * q * PLANE + t * IWP + u];
+                for (int t = 0; t < 6; ++t) xin[t] = bb[4 * q * PLANE + t * IWP + u];
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) aw[ky] = Aw[((ky * 4 + u) * Q + q) * 64 + lane];
 #pragma unroll
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(kBlock) void conv_pair8_k(const IgemmArgs A, const 
             }
             if (valid) sta4<AT>(outp + pix * M + ch0, make_float4(v[0], v[1], v[2], v[3]));
         }
+      }
     };
 
     // software pipeline over the block's tiles: while tile t is computed from LDS, tile t+1 waits in one register
@@ -167,8 +175,12 @@ __global__ __launch_bounds__(kBlock) void conv_pair8_k(const IgemmArgs A, const 
                 for (int i = 0; i < 4; ++i) { red[wave * 16 + ch0 + i] = s1[i]; red[wave * 16 + 8 + ch0 + i] = s2[i]; }
             }
             __syncthreads();
-            if (tid < 2 * M)               // [0,8) = sum, [8,16) = second statistic; fixed summation order
-                A.part[(size_t)blockIdx.x * (2 * M) + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+            if (tid < 2 * M) {             // [0,8) = sum, [8,16) = second statistic; fixed summation order
+                float t = red[tid];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) t += red[w * 16 + tid];
+                A.part[(size_t)blockIdx.x * (2 * M) + tid] = t;
+            }
         }
     }
 }

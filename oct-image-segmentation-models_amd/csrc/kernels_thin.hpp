@@ -50,9 +50,9 @@ struct TileWalk {
 // with the consumer-side transform (BN affine + ReLU, dropout, concat of two sources, zero padding).
 // Set up ONCE per thread: a thread always serves the same channel quad, so its source tensor, BN affine and LDS plane
 // are tile-invariant; per slot k only the packed local pixel (ly, lx) is kept. ----
-template <int CMAX, int IH, int IW, int IWP, int PLANE, int AMODE, int TH, int TW, typename AT>
+template <int CMAX, int IH, int IW, int IWP, int PLANE, int AMODE, int TH, int TW, typename AT, int NT = kBlock>
 struct ThinStager {
-    static constexpr int Q = CMAX / 4, PPI = kBlock / Q, NPIX = IH * IW, NPF = (NPIX + PPI - 1) / PPI;
+    static constexpr int Q = CMAX / 4, PPI = NT / Q, NPIX = IH * IW, NPF = (NPIX + PPI - 1) / PPI;
     const AT* __restrict__ src; float* lds_q;
     int Csrc, cc; bool cok;
     float4 fa, fb;

@@ -23,6 +23,7 @@ namespace {
 
 thread_local std::string g_err;
 int g_thin_min_tiles = 2048;      // pixel tiles from which 8-channel layers use the VALU thin kernel
+int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
 int g_persist_min_tiles = 2048;   // pixel tiles from which thin single-chunk convs use the persistent pipelined kernel
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -313,35 +314,38 @@ int launch_igemm_p(IgemmArgs a, int B, hipStream_t s, const char* layer, double 
     return 0;
 }
 
-// resident blocks per CU of a kernel (queried once per instantiation) -> grid of a persistent launch
-template <typename K>
-int resident_blocks(K kern, int fallback) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kBlock, 0) != hipSuccess || nb < 1) nb = fallback;
-    return nb;
-}
-
 #ifndef PAIR_DEPTH
 #define PAIR_DEPTH 1     // register prefetch depth of the 8-input-channel pair kernel (tiles in flight beyond the one in LDS)
 #endif
 // pixel-pair MFMA kernel for 3x3 layers with 8 output channels (see kernels_pair.hpp)
-template <int EPI>
-int launch_pair8(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    a.tiles_x = cdiv(a.Wo, 64); a.tiles = a.tiles_x * cdiv(a.Ho, 8); a.total_tiles = B * a.tiles;
-    static int occ[2][2] = {{0, 0}, {0, 0}};
-    const int wide = a.Cin <= 8 ? 0 : 1, bf = a.act_bf16 ? 1 : 0;
-    if (!occ[wide][bf]) {
-        if (wide) AT_DISPATCH(bf, occ[wide][bf] = resident_blocks(conv_pair8_k<EPI, 16, 1, AT>, 3));
-        else AT_DISPATCH(bf, occ[wide][bf] = resident_blocks(conv_pair8_k<EPI, 8, PAIR_DEPTH, AT>, 4));
+template <int EPI, int CMAX, int NWY, int NWX, int RPW>
+int launch_pair8_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+    constexpr int NT = 64 * NWY * NWX, DEPTH = PAIR_DEPTH;
+    a.tiles_x = cdiv(a.Wo, 32 * NWX); a.tiles = a.tiles_x * cdiv(a.Ho, 4 * RPW * NWY); a.total_tiles = B * a.tiles;
+    static int occ[2] = {0, 0};
+    const int bf = a.act_bf16 ? 1 : 0;
+    if (!occ[bf]) {
+        int nb = 0;
+        AT_DISPATCH(bf, if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pair8_k<EPI, CMAX, DEPTH, NWY, NWX, RPW, AT>, NT, 0) != hipSuccess) nb = 0);
+        occ[bf] = nb < 1 ? 2 : nb;
     }
-    const int nblk = std::min(a.total_tiles, occ[wide][bf] * 256);
-    char nm[64]; snprintf(nm, sizeof nm, "conv_pair8_k<%d,%d,%d,%s>", EPI, wide ? 16 : 8, wide ? 1 : PAIR_DEPTH, AT_NAME(a.act_bf16));
+    const int nblk = std::min(a.total_tiles, occ[bf] * 256);
+    char nm[80]; snprintf(nm, sizeof nm, "conv_pair8_k<%d,%d,%d,%d,%d,%d,%s>", EPI, CMAX, DEPTH, NWY, NWX, RPW, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, layer, flops, bytes);
-    if (!wide) AT_DISPATCH(bf, conv_pair8_k<EPI, 8, PAIR_DEPTH, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
-    else AT_DISPATCH(bf, conv_pair8_k<EPI, 16, 1, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
+    AT_DISPATCH(bf, conv_pair8_k<EPI, CMAX, DEPTH, NWY, NWX, RPW, AT><<<nblk, NT, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
     HIP_OK(hipGetLastError());
     *rows = nblk;
     return 0;
+}
+template <int EPI>
+int launch_pair8(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+    const int geo = g_pair_geo;    // NWY*100 + NWX*10 + RPW
+    if (a.Cin <= 8) {
+        if (geo == 111) return launch_pair8_geo<EPI, 8, 1, 1, 1>(a, B, s, layer, flops, bytes, rows);
+        return launch_pair8_geo<EPI, 8, 2, 2, 1>(a, B, s, layer, flops, bytes, rows);
+    }
+    if (geo == 111) return launch_pair8_geo<EPI, 16, 1, 1, 1>(a, B, s, layer, flops, bytes, rows);
+    return launch_pair8_geo<EPI, 16, 2, 2, 1>(a, B, s, layer, flops, bytes, rows);
 }
 
 // VALU kernel for 8-output-channel layers (see kernels_thin.hpp)
@@ -588,8 +592,17 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
     const double by = in_bytes(l, B, x_is_u8, es) + px * l.cout * es;   // conv input once + dz once
     const bool up = l.src == SRC_UP;
     int rc = 0;
-    if (p.kind == 0) {
-        rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by);   // 1-channel (or odd-channel) first layer
+    if (p.kind == 0 && l.cin == 1 && l.cout == 8 && l.kh == 3 && !(a.flags & (F_AFF | F_DROP | F_TWO | F_UP))) {
+        // the real first layer: streaming reduction kernel (kernels_bwd.hpp)
+        const int tx = cdiv(l.W, 128), tiles = tx * cdiv(l.H, 8), total = B * tiles;
+        const int grid = std::min(total, a.npb);
+        a.npb = grid;
+        const int bf = a.act_bf16;
+        ProfScope ps(s, bf ? "conv_dw_first_k<unsigned short>" : "conv_dw_first_k<float>", l.name, fl, by);
+        AT_DISPATCH(bf, conv_dw_first_k<AT><<<grid, kBlock, 0, s>>>(a, tx, tiles, total));
+        HIP_OK(hipGetLastError());
+    } else if (p.kind == 0) {
+        rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by);   // other 1-channel / odd-channel first layers
     } else {
         dim3 grid(p.npb, cdiv(l.cin, p.cic), cdiv(l.cout, p.coc)), block(kBlock);
         char nm[64];
@@ -943,6 +956,7 @@ int oct_boundary_maps(const unsigned char* labels, int B, int H, int W, int n_cl
 int oct_set_option(const char* name, int value) {
     if (!name) return fail(-1, "null option name");
     if (!strcmp(name, "igemm_persistent_min_tiles")) { g_persist_min_tiles = value < 1 ? 1 : value; return 0; }
+    if (!strcmp(name, "pair8_geometry")) { if (value != 221 && value != 111) return fail(-1, "pair8_geometry must be 221 or 111"); g_pair_geo = value; return 0; }
     if (!strcmp(name, "pair8_min_tiles")) { g_pair_min_tiles = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "thin8_min_tiles")) { g_thin_min_tiles = value < 1 ? 1 : value; return 0; }
     return fail(-1, std::string("unknown option: ") + name);

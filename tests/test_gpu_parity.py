@@ -53,18 +53,21 @@ MARGIN_SEED = {CASES[0]: 97, CASES[1]: 13, CASES[2]: 28, CASES[3]: 75}
 DROP_STEP = 3
 
 
-@pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma"])
+@pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant for the thin layers (the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels are otherwise only chosen on large grids)."""
     from oct_image_segmentation_models_amd import _hip
-    _hip.set_option("igemm_persistent_min_tiles", 1 if request.param == "persistent" else 1 << 30)
-    _hip.set_option("thin8_min_tiles", 1 if request.param in ("thin8_valu", "pair8_mfma") else 1 << 30)
-    _hip.set_option("pair8_min_tiles", 1 if request.param == "pair8_mfma" else 1 << 30)
-    yield request.param
+    v = request.param
+    _hip.set_option("igemm_persistent_min_tiles", 1 if v == "persistent" else 1 << 30)
+    _hip.set_option("thin8_min_tiles", 1 if v == "thin8_valu" or v.startswith("pair8") else 1 << 30)
+    _hip.set_option("pair8_min_tiles", 1 if v.startswith("pair8") else 1 << 30)
+    _hip.set_option("pair8_geometry", int(v[-3:]) if v[-3:].isdigit() else 221)
+    yield v
     _hip.set_option("igemm_persistent_min_tiles", 2048)
     _hip.set_option("thin8_min_tiles", 2048)
     _hip.set_option("pair8_min_tiles", 2048)
+    _hip.set_option("pair8_geometry", 221)
 
 
 @pytest.mark.parametrize("case", CASES)
