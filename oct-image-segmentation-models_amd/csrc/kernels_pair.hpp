@@ -91,6 +91,7 @@ __global__ __launch_bounds__(64 * NWY * NWX) void conv_pair8_k(const IgemmArgs A
         f32x4 acc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = f32x4{bias[0], bias[1], bias[2], bias[3]};
+        __builtin_amdgcn_s_setprio(2);      // waves in their MFMA phase issue ahead of waves that are staging
 #pragma unroll 1
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(64 * NWY * NWX) void conv_pair8_k(const IgemmArgs A
                         acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[ky], xin[r + ky], acc[r], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -209,9 +209,14 @@ class Model:
             self._engine.set_weights(weights)
 
     def save(self, filepath, **kwargs) -> Path:
-        """Write architecture config + weights (Keras ``get_weights()`` order) to an ``.npz`` container."""
+        """Write architecture config + weights (Keras ``get_weights()`` order).  A ``.h5`` / ``.hdf5`` path is
+        written in the Keras HDF5 weight layout when ``h5py`` is importable (``common/keras_h5.py``: loadable by the
+        reference's ``UNet(**cfg).build_model().load_weights``); otherwise -- and for any other suffix -- an ``.npz``
+        container is written (``foo.hdf5`` becomes ``foo.hdf5.npz``)."""
+        from ..common import keras_h5
         path = Path(filepath)
-        if path.suffix != ".npz":
+        as_h5 = path.suffix in (".h5", ".hdf5") and keras_h5.have_h5py()
+        if not as_h5 and path.suffix != ".npz":
             path = Path(str(path) + ".npz")
         w = self.get_weights()
         if parallel.world_size() > 1 and self._engine is not None:
@@ -225,7 +230,10 @@ class Model:
         payload["config_json"] = np.array(json.dumps(self.config))
         if parallel.env_rank()[0] == 0:
             path.parent.mkdir(parents=True, exist_ok=True)
-            np.savez(path, **payload)
+            if as_h5:
+                keras_h5.export_keras_h5(path, w, self.config)
+            else:
+                np.savez(path, **payload)
         return path
 
     # ---- training -------------------------------------------------------------------------------------
@@ -350,7 +358,17 @@ class Model:
 def load_model(path) -> Model:
     """Counterpart of ``tf.keras.models.load_model(compile=False)`` for files written by ``Model.save``.
     Only arrays and JSON are read (``allow_pickle=False``)."""
+    from ..common import keras_h5
     path = Path(path)
+    if keras_h5.is_keras_h5_path(path):
+        # a Keras HDF5 checkpoint (written by the reference's ModelCheckpoint, or by Model.save with h5py present)
+        config = keras_h5.read_embedded_config(path)
+        if config is None:
+            with open(path.parent / "model_config.json", "r") as fh:     # reference: common/utils.py:68-69
+                config = json.load(fh)
+        m = Model(name=config.get("name", "unet") if isinstance(config.get("name"), str) else "unet", config=config)
+        m.set_weights(keras_h5.import_keras_h5(path, config))
+        return m
     if not path.exists() and Path(str(path) + ".npz").exists():
         path = Path(str(path) + ".npz")
     with np.load(path, allow_pickle=False) as z:
