@@ -82,6 +82,74 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_k(const PoolBwdArgs A) {
     block_reduce_store<C_T>(s2, red, out + A.C + c0, C_T);
 }
 
+// Same operation with a FLAT thread mapping (pooled pixel x channel quad, quad fastest): a wave touches contiguous
+// bytes whatever the channel count (the tiled kernel above gives a block one 4-channel slice, i.e. 16 useful bytes per
+// 4*C-byte pixel -- 1.25 TB/s at C = 64).  Needs C/4 a power of two <= 64: a thread's quad is then the same in every
+// grid-stride iteration, its statistics stay in registers, and lanes with equal quad are summed by xor-shuffles.
+// grid (nblk); one statistics row per block.
+template <typename AT>
+__global__ __launch_bounds__(kBlock) void pool_bwd_flat_k(const PoolBwdArgs A, int B) {
+    __shared__ float sh[4][64][8];
+    const int C4 = A.C >> 2, Ho = A.H >> 1, Wo = A.W >> 1;
+    const size_t n = (size_t)B * Ho * Wo * C4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = 4 * (tid % C4);
+    float a[4], bb[4], mean[4], rstd[4], s1[4], s2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = A.bn[BN_A * A.C + c + k]; bb[k] = A.bn[BN_B * A.C + c + k];
+        mean[k] = A.bn[BN_MEAN * A.C + c + k]; rstd[k] = A.bn[BN_RSTD * A.C + c + k];
+        s1[k] = 0.f; s2[k] = 0.f;
+    }
+    const AT* Az = reinterpret_cast<const AT*>(A.z); AT* Ag = reinterpret_cast<AT*>(A.g);
+    const AT* Agp = reinterpret_cast<const AT*>(A.gp);
+    for (size_t i = (size_t)blockIdx.x * kBlock + tid; i < n; i += (size_t)gridDim.x * kBlock) {
+        size_t r = i / C4;
+        const int xo = (int)(r % Wo); r /= Wo;
+        const int yo = (int)(r % Ho); const int b = (int)(r / Ho);
+        const float4 gq = lda4<AT>(Agp + (((size_t)b * Ho + yo) * Wo + xo) * A.C + c);
+        const float gpv[4] = {gq.x, gq.y, gq.z, gq.w};
+        size_t off[4]; float zv[4][4], gd[4][4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            off[w] = (((size_t)b * A.H + 2 * yo + (w >> 1)) * A.W + 2 * xo + (w & 1)) * A.C + c;
+            const float4 t = lda4<AT>(Az + off[w]), u = lda4<AT>(Ag + off[w]);
+            zv[w][0] = t.x; zv[w][1] = t.y; zv[w][2] = t.z; zv[w][3] = t.w;
+            gd[w][0] = u.x; gd[w][1] = u.y; gd[w][2] = u.z; gd[w][3] = u.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float yv[4]; int am = 0; float best = -1.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                yv[w] = fmaxf(fmaf(a[k], zv[w][k], bb[k]), 0.f);
+                if (yv[w] > best) { best = yv[w]; am = w; }     // first maximum in row-major window order
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float gt = yv[w] > 0.f ? gd[w][k] + (w == am ? gpv[k] : 0.f) : 0.f;
+                s1[k] += gt; s2[k] += gt * ((zv[w][k] - mean[k]) * rstd[k]);
+                gd[w][k] = gt;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sta4<AT>(Ag + off[w], make_float4(gd[w][0], gd[w][1], gd[w][2], gd[w][3]));
+    }
+    for (int o = C4; o < 64; o <<= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s1[k] += __shfl_xor(s1[k], o, 64); s2[k] += __shfl_xor(s2[k], o, 64); }
+    if (lane < C4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sh[wave][lane][k] = s1[k]; sh[wave][lane][4 + k] = s2[k]; }
+    }
+    __syncthreads();
+    if (tid < A.C) {
+        const int qq = tid >> 2, k = tid & 3;
+        float* out = A.part + (size_t)blockIdx.x * (2 * A.C);
+        out[tid] = (sh[0][qq][k] + sh[1][qq][k]) + (sh[2][qq][k] + sh[3][qq][k]);           // fixed order
+        out[A.C + tid] = (sh[0][qq][4 + k] + sh[1][qq][4 + k]) + (sh[2][qq][4 + k] + sh[3][qq][4 + k]);
+    }
+}
+
 // ---- BN backward finalize + apply -------------------------------------------------------------------------------
 struct BnBwdFinArgs {
     const float* part; int nblk, C; double count;

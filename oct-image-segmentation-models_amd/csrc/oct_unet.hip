@@ -700,10 +700,21 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
                 PoolBwdArgs pb{};
                 pb.gp = h->gpooled[l.level - 1]; pb.z = p.z; pb.bn = p.bn; pb.g = p.g; pb.part = h->stat_part;
                 pb.act_bf16 = h->cfg.dtype; pb.H = p.H; pb.W = p.W; pb.C = p.cout; pb.tiles_x = cdiv(p.W / 2, kTileX); pb.tiles = tiles_of(p.H / 2, p.W / 2);
+                const int bf = h->cfg.dtype, c4 = p.cout / 4;
+                const double pbytes = (double)B * p.H * p.W * p.cout * (bf ? 2 : 4) * 3.25;
+                if (c4 >= 1 && c4 <= 64 && (c4 & (c4 - 1)) == 0) {     // flat, channel-contiguous mapping
+                    const size_t items = (size_t)B * (p.H / 2) * (p.W / 2) * c4;
+                    const size_t cap = (size_t)B * cdiv(p.H, 2) * cdiv(p.W, kTileX);     // statistic rows carve() guarantees
+                    const int grid = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(cdiv((int)items, kBlock), 2048), cap));
+                    ProfScope ps(s, bf ? "pool_bwd_flat_k<unsigned short>" : "pool_bwd_flat_k<float>", p.name, 0, pbytes);
+                    AT_DISPATCH(bf, pool_bwd_flat_k<AT><<<grid, kBlock, 0, s>>>(pb, B));
+                    HIP_OK(hipGetLastError());
+                    pending_nblk = grid;
+                    break;
+                }
                 const int c_t = 4;
                 dim3 grid(pb.tiles, p.cout / c_t, B);
-                const int bf = h->cfg.dtype;
-                ProfScope ps(s, bf ? "pool_bwd_k<4,unsigned short>" : "pool_bwd_k<4,float>", p.name, 0, (double)B * p.H * p.W * p.cout * (bf ? 2 : 4) * 3.25);
+                ProfScope ps(s, bf ? "pool_bwd_k<4,unsigned short>" : "pool_bwd_k<4,float>", p.name, 0, pbytes);
                 AT_DISPATCH(bf, pool_bwd_k<4, AT><<<grid, kBlock, 0, s>>>(pb));
                 HIP_OK(hipGetLastError());
                 pending_nblk = B * pb.tiles;
