@@ -453,8 +453,17 @@ __global__ __launch_bounds__(kBlock) void reduce_all_k(const ReduceAllArgs A) {
     const int jw = E.jw, nq = kBlock / jw, col = threadIdx.x % jw, q = threadIdx.x / jw;
     const size_t j = (size_t)(blockIdx.x - E.blk_start) * jw + col;
     double s = 0;
-    if (j < E.stride)
-        for (int p = q; p < E.npb; p += nq) s += E.part[(size_t)p * E.stride + j];
+    if (j < E.stride) {
+        const float* __restrict__ src = E.part + j;
+        int p = q;
+        for (; p + 7 * nq < E.npb; p += 8 * nq) {      // 8 independent loads in flight per thread, fixed summation order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(p + k * nq) * E.stride];
+            s += (((double)v[0] + v[1]) + ((double)v[2] + v[3])) + (((double)v[4] + v[5]) + ((double)v[6] + v[7]));
+        }
+        for (; p < E.npb; p += nq) s += src[(size_t)p * E.stride];
+    }
     sh[q * jw + col] = s;
     __syncthreads();
     if (q == 0 && j < E.stride) {

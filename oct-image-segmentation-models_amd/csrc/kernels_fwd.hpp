@@ -119,6 +119,64 @@ __global__ __launch_bounds__(kBlock) void conv_fwd_k(const ConvFwdArgs A) {
     }
 }
 
+// ---- first layer, the real configuration (1 input channel -- uint8 through the /255 table, or f32 --, 8 output
+// channels, 3x3).  Output-write bound (32 B/pixel): a PERSISTENT block walks 8 x 128 tiles, image tile in LDS, the 72
+// weights wave-uniform, 4 pixels per thread with fully coalesced 32 B stores; BN statistics stay in registers across
+// tiles and are reduced ONCE per block (the tile-per-block kernel pays two block reductions per 256 pixels and hands
+// the finalize 16 384 partial rows at B = 32).  grid (nblk); statistics row per block.
+template <typename AT>
+__global__ __launch_bounds__(kBlock) void conv_first_fwd_k(const ConvFwdArgs A, int x_is_u8, int tiles_x, int tiles, int total_tiles,
+                                                          const float* __restrict__ wgt, const float* __restrict__ bias) {
+    constexpr int TH = 8, TW = 128, XH = TH + 2, XW = TW + 2;
+    __shared__ float Xs[XH * XW];
+    __shared__ float red[256];
+    const int t = threadIdx.x, xl = t & 31, row = t >> 5;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+        const int b = tl / tiles, tile = tl % tiles;
+        const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+        __syncthreads();
+        for (int i = t; i < XH * XW; i += kBlock) {
+            const int cy = i / XW, cx = i % XW, iy = y0 + cy - 1, ix = x0 + cx - 1;
+            float v = 0.f;
+            if (iy >= 0 && iy < A.H && ix >= 0 && ix < A.W) {
+                const size_t pix = ((size_t)b * A.H + iy) * A.W + ix;
+                v = x_is_u8 ? c_u8_lut[reinterpret_cast<const unsigned char*>(A.x0)[pix]] : reinterpret_cast<const float*>(A.x0)[pix];
+            }
+            Xs[i] = v;
+        }
+        __syncthreads();
+        const int y = y0 + row;
+#pragma unroll
+        for (int k = 0; k < TW / 32; ++k) {
+            const int xx = xl + 32 * k, x = x0 + xx;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = bias[j];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float xv = Xs[(row + tap / 3) * XW + xx + tap % 3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wgt[tap * 8 + j], acc[j]);
+            }
+            if (y < A.H && x < A.W) {
+                AT* zp = reinterpret_cast<AT*>(A.z) + (((size_t)b * A.H + y) * A.W + x) * 8;
+                sta4<AT>(zp, make_float4(acc[0], acc[1], acc[2], acc[3]));
+                sta4<AT>(zp + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
+            }
+        }
+    }
+    if (A.part) {
+        float* out = A.part + (size_t)blockIdx.x * 16;
+        block_reduce_store<8>(s1, red, out, 8);
+        block_reduce_store<8>(s2, red, out + 8, 8);
+    }
+}
+
 // ---- BN finalize (training): partials -> mean / biased var -> (a, b); moving-stat update -----------------
 struct BnFinArgs {
     const float* part;  // [nblk][2*C]

@@ -426,7 +426,15 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
         g.part = a.part; g.drop = a.drop; g.act_bf16 = h->cfg.dtype;
         rc = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows)
                              : launch_igemm<3, A_NORMAL, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows);
-    } else if (l.src == SRC_INPUT) {   // first layer: 1 (or odd) input channels, uint8 /255 table on load -> VALU direct conv
+    } else if (l.src == SRC_INPUT && l.cin == 1 && l.cout == 8 && l.kh == 3) {   // the real first layer: persistent streaming kernel
+        const int tx = cdiv(l.W, 128), tiles = tx * cdiv(l.H, 8), total = B * tiles;
+        const int grid = std::min(total, 2048);      // <= B*ceil(H/2)*ceil(W/32) statistic rows guaranteed by carve()
+        const int bf = h->cfg.dtype;
+        ProfScope ps(s, bf ? "conv_first_fwd_k<unsigned short>" : "conv_first_fwd_k<float>", l.name, fl, by);
+        AT_DISPATCH(bf, conv_first_fwd_k<AT><<<grid, kBlock, 0, s>>>(a, x_is_u8, tx, tiles, total, a.w, a.bias));
+        HIP_OK(hipGetLastError());
+        stat_rows = grid; rc = 0;
+    } else if (l.src == SRC_INPUT) {   // other first layers (odd channel counts): uint8 /255 table on load -> VALU direct conv
         rc = x_is_u8 ? launch_conv_fwd_co<3, F_U8>(a, B, s, l.name, fl, by) : launch_conv_fwd_co<3, 0>(a, B, s, l.name, fl, by);
     } else {
         return fail(-3, "conv_forward: channel count not a multiple of 4");

@@ -31,7 +31,7 @@ def trained(tmp_path_factory):
     tp = TrainingParams(model_architecture="unet", training_dataset_path=root / "data.hdf5", initial_model=None,
                         results_location=root / "results", opt_con=optimizers.Adam, opt_params={"learning_rate": 4e-3},
                         loss="dice_loss_macro", metric="dice_coef_macro", epochs=EPOCHS, batch_size=4,
-                        model_hyperparameters={"pool_layers": 3}, patience=50, seed=7)
+                        model_hyperparameters={"pool_layers": 3}, patience=EPOCHS + 1, seed=7)   # no early stop: the file/epoch bookkeeping below needs all EPOCHS
     res = train_model(tp, None)
     return root, res, (te_i, te_l)
 
