@@ -143,6 +143,8 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   thin-layer kernel instead of the (half-padded) 16x16 MFMA kernel.
  *   "pair8_min_tiles" (default 2048): number of pixel tiles from which 3x3 convs with 8 output channels run on the
  *   pixel-pair MFMA kernel (takes precedence over the VALU kernel).
+ *   "dwpair8_enable" (default 1): backward-weights of 3x3 layers with 8 output channels on the pixel-pair kernel
+ *   (0 = the padded 16-column kernel).
  *   "pair8_geometry" (NWY*100 + NWX*10 + RPW in {221, 111}, default 221): waves per block (rows x columns)
  *   and 4-row groups per wave of that kernel; its tile is (4*RPW*NWY) x (32*NWX) pixels. */
 int oct_set_option(const char* name, int value);

@@ -37,7 +37,7 @@ __device__ __forceinline__ float4 x4_xform(const ConvBwdWArgs& A, float4 v, size
     return v;
 }
 
-template <int CIC, int COC, int IH, int IW, bool UP, int KH, int TH, typename AT>
+template <int CIC, int COC, int IH, int IW, bool UP, int KH, int TH, typename AT, int XSTRIDE = CIC>
 struct TileStager {
     static constexpr int NX = (IH * IW * (CIC / 4) + kBlock - 1) / kBlock;   // float4 per thread, X tile
     static constexpr int ND = (TH * 32 * (COC / 4) + kBlock - 1) / kBlock;   // float4 per thread, dz tile
@@ -80,7 +80,7 @@ struct TileStager {
                 float4 v = xr[k];
                 if (gy >= 0 && gy < Hs && gx >= 0 && gx < Ws && c < A.Cin)
                     v = x4_xform(A, v, ((size_t)b * Hs + gy) * Ws + gx, c);   // out-of-range stays exactly zero
-                st4(Xs + (ly * IW + lx) * CIC + 4 * q, v);
+                st4(Xs + (ly * IW + lx) * XSTRIDE + 4 * q, v);
             }
         }
 #pragma unroll
@@ -195,6 +195,97 @@ __global__ __launch_bounds__(kBlock) void conv_dw16_k(const ConvBwdWArgs A) {
             out[((size_t)tap * A.Cin + ci0 + ci) * A.Cout + co0 + col] = s;
     }
     bias_reduce<16>(A, lds, bsum, out + wsize, co0, blockIdx.y == 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 layers with 8 OUTPUT channels (full resolution): pixel-pair packing, the backward-weights counterpart of
+// kernels_pair.hpp.  With N = 8 output channels a 16-column MFMA is half padding; here the 16 columns are
+// (pixel parity j, co) and K runs over pixel PAIRS (2n, 2n+1) of a row:
+//     D[(ky,u,ci)][(j,co)] = sum_{y,n} X(y+ky-1, 2n+u-1)[ci] * dz(y, 2n+j)[co],   u = 0..3 (window column of the pair)
+//     dW[ky][kx][ci][co]   = D[(ky,kx,ci)][(0,co)] + D[(ky,kx+1,ci)][(1,co)]
+// 12*CIC rows (6 or 12 M tiles of 16), every column useful: 9/12 = 75 % useful MFMA work (45-50 % for the padded
+// form), i.e. 0.75 (CIC = 8) / 1.5 (CIC = 16) MFMAs per pixel instead of 1.25 / 2.25.
+// Operands straight from the NHWC LDS tiles, conflict-free: B = dz[(row, 2n+j)][co] -- 64 lanes read 64 consecutive
+// floats; A = X[(row+ky, 2n+u)][ci] -- consecutive for CIC = 8, pixel stride padded to 20 floats for CIC = 16.
+// Every wave owns all M tiles for a quarter of the tile's pixel rows; 4-wave sum through LDS at the end.
+// grid (npb, ceil(Cin/CIC), 1); requires Cout == 8, KH == 3, not an up-conv.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CIC, typename AT>
+__global__ __launch_bounds__(kBlock) void conv_dwpair8_k(const ConvBwdWArgs A) {
+    constexpr int KH = 3, TH = 8, TW = 32, MROWS = 12 * CIC, MTILES = MROWS / 16, XST = CIC == 16 ? 20 : CIC;
+    constexpr int IH = TH + 2, IW = TW + 2;
+    constexpr int XS = IH * IW * XST, DS = TH * TW * 8, RED = MROWS * 16;
+    constexpr int LDSN = (XS + DS > 4 * RED ? XS + DS : 4 * RED) > 1024 ? (XS + DS > 4 * RED ? XS + DS : 4 * RED) : 1024;
+    __shared__ float lds[LDSN];
+    float* Xs = lds; float* Ds = lds + XS;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci0 = blockIdx.y * CIC;
+
+    // A row of M tile mt held by this lane: m = mt*16 + i -> (ky, u, ci);  LDS offset of X(ky, u)[ci] relative to the pair
+    int aoff[MTILES];
+#pragma unroll
+    for (int mt = 0; mt < MTILES; ++mt) {
+        const int m = mt * 16 + i, ci = m % CIC, ku = m / CIC, u = ku & 3, ky = ku >> 2;
+        aoff[mt] = (ky * IW + u) * XST + ci;
+    }
+    f32x4 acc[MTILES];
+#pragma unroll
+    for (int mt = 0; mt < MTILES; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    TileStager<CIC, 8, IH, IW, false, KH, TH, AT, XST> st;
+    auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
+        b = tl / A.tiles; const int tile = tl % A.tiles;
+        x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;
+    };
+    {
+        int b, y0, x0;
+        if ((int)blockIdx.x < A.total_tiles) { tile_of(blockIdx.x, b, y0, x0); st.load(A, b, y0, x0, ci0, 0); }
+    }
+    for (int tl = blockIdx.x; tl < A.total_tiles; tl += A.npb) {
+        int b, y0, x0;
+        tile_of(tl, b, y0, x0);
+        __syncthreads();                                   // every wave is done with the previous tile's LDS image
+        st.store(A, Xs, Ds, b, y0, x0, ci0, bsum);
+        __syncthreads();
+        if (tl + A.npb < A.total_tiles) {                  // next tile's loads fly while this tile computes
+            int nb, ny0, nx0;
+            tile_of(tl + A.npb, nb, ny0, nx0);
+            st.load(A, nb, ny0, nx0, ci0, 0);
+        }
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs) {
+            const int rr = wave + 4 * rs;
+#pragma unroll 2
+            for (int ks = 0; ks < TW / 8; ++ks) {
+                const int n = 4 * ks + kk;                  // pixel pair of this lane's K slot
+                const float bv = Ds[(rr * TW + 2 * n) * 8 + i];                 // i = (j, co): pixel 2n + j, channel co
+                const float* xa = Xs + (rr * IW + 2 * n) * XST;
+#pragma unroll
+                for (int mt = 0; mt < MTILES; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[aoff[mt]], bv, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- 4-wave sum through LDS into D[m][16], then fold the two pixel parities into the 3x3 taps ----
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MTILES; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[wave * RED + (mt * 16 + 4 * kk + r) * 16 + i] = acc[mt][r];    // D row = 4*(lane>>4)+r, col = lane&15
+    __syncthreads();
+    for (int idx = tid; idx < RED; idx += kBlock) lds[idx] = (lds[idx] + lds[RED + idx]) + (lds[2 * RED + idx] + lds[3 * RED + idx]);
+    __syncthreads();
+    const size_t wsize = (size_t)9 * A.Cin * A.Cout;
+    float* out = A.part + (size_t)blockIdx.x * (wsize + A.Cout);
+    for (int idx = tid; idx < 9 * CIC * 8; idx += kBlock) {
+        const int co = idx & 7, ci = (idx >> 3) % CIC, tap = idx / (8 * CIC), ky = tap / 3, kx = tap % 3;
+        if (ci0 + ci < A.Cin)
+            out[((size_t)tap * A.Cin + ci0 + ci) * A.Cout + co] =
+                lds[((ky * 4 + kx) * CIC + ci) * 16 + co] + lds[((ky * 4 + kx + 1) * CIC + ci) * 16 + 8 + co];
+    }
+    bias_reduce<8>(A, lds, bsum, out + wsize, 0, blockIdx.y == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

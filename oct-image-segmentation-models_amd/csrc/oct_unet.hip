@@ -23,6 +23,7 @@ namespace {
 
 thread_local std::string g_err;
 int g_thin_min_tiles = 2048;      // pixel tiles from which 8-channel layers use the VALU thin kernel
+int g_dwpair8 = 1;                // 3x3 layers with 8 output channels: pixel-pair backward-weights kernel (0 = padded 16-column kernel)
 int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
 int g_persist_min_tiles = 2048;   // pixel tiles from which thin single-chunk convs use the persistent pipelined kernel
@@ -614,10 +615,15 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
     } else {
         dim3 grid(p.npb, cdiv(l.cin, p.cic), cdiv(l.cout, p.coc)), block(kBlock);
         char nm[64];
-        if (p.kind == 16) snprintf(nm, sizeof nm, "conv_dw16_k<%d,%d,%s,%s>", l.kh, p.cic, up ? "true" : "false", AT_NAME(a.act_bf16));
+        if (p.kind == 16 && !up && l.cout == 8 && l.kh == 3 && g_dwpair8) snprintf(nm, sizeof nm, "conv_dwpair8_k<%d,%s>", p.cic, AT_NAME(a.act_bf16));
+        else if (p.kind == 16) snprintf(nm, sizeof nm, "conv_dw16_k<%d,%d,%s,%s>", l.kh, p.cic, up ? "true" : "false", AT_NAME(a.act_bf16));
         else snprintf(nm, sizeof nm, "conv_dw32_k<%d,%d,%s,%d,%s>", l.kh, p.cic, up ? "true" : "false", p.th, AT_NAME(a.act_bf16));
         ProfScope ps(s, nm, l.name, fl, by);
-        if (p.kind == 16) {
+        if (p.kind == 16 && !up && l.cout == 8 && l.kh == 3 && g_dwpair8) {
+            grid = dim3(p.npb, cdiv(l.cin, p.cic), 1);
+            if (p.cic == 16) AT_DISPATCH(a.act_bf16, conv_dwpair8_k<16, AT><<<grid, block, 0, s>>>(a));
+            else AT_DISPATCH(a.act_bf16, conv_dwpair8_k<8, AT><<<grid, block, 0, s>>>(a));
+        } else if (p.kind == 16) {
             if (up) { if (p.cic == 16) AT_DISPATCH(a.act_bf16, conv_dw16_k<2, 16, true, AT><<<grid, block, 0, s>>>(a)); else AT_DISPATCH(a.act_bf16, conv_dw16_k<2, 8, true, AT><<<grid, block, 0, s>>>(a)); }
             else { if (p.cic == 16) AT_DISPATCH(a.act_bf16, conv_dw16_k<3, 16, false, AT><<<grid, block, 0, s>>>(a)); else AT_DISPATCH(a.act_bf16, conv_dw16_k<3, 8, false, AT><<<grid, block, 0, s>>>(a)); }
         } else {
@@ -975,6 +981,7 @@ int oct_boundary_maps(const unsigned char* labels, int B, int H, int W, int n_cl
 int oct_set_option(const char* name, int value) {
     if (!name) return fail(-1, "null option name");
     if (!strcmp(name, "igemm_persistent_min_tiles")) { g_persist_min_tiles = value < 1 ? 1 : value; return 0; }
+    if (!strcmp(name, "dwpair8_enable")) { g_dwpair8 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "pair8_geometry")) { if (value != 221 && value != 111) return fail(-1, "pair8_geometry must be 221 or 111"); g_pair_geo = value; return 0; }
     if (!strcmp(name, "pair8_min_tiles")) { g_pair_min_tiles = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "thin8_min_tiles")) { g_thin_min_tiles = value < 1 ? 1 : value; return 0; }

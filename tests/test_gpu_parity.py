@@ -53,7 +53,7 @@ MARGIN_SEED = {CASES[0]: 97, CASES[1]: 13, CASES[2]: 28, CASES[3]: 75}
 DROP_STEP = 3
 
 
-@pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111"])
+@pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111", "dw16_padded"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant for the thin layers (the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels are otherwise only chosen on large grids)."""
@@ -63,7 +63,9 @@ def variant(request):
     _hip.set_option("thin8_min_tiles", 1 if v == "thin8_valu" or v.startswith("pair8") else 1 << 30)
     _hip.set_option("pair8_min_tiles", 1 if v.startswith("pair8") else 1 << 30)
     _hip.set_option("pair8_geometry", int(v[-3:]) if v[-3:].isdigit() else 221)
+    _hip.set_option("dwpair8_enable", 0 if v == "dw16_padded" else 1)
     yield v
+    _hip.set_option("dwpair8_enable", 1)
     _hip.set_option("igemm_persistent_min_tiles", 2048)
     _hip.set_option("thin8_min_tiles", 2048)
     _hip.set_option("pair8_min_tiles", 2048)
