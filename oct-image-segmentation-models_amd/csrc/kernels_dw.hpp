@@ -351,6 +351,7 @@ __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
                 }
             };
             float an[UPW], bn;
+            __builtin_amdgcn_s_setprio(2);
             load(0, an, bn);
 #pragma unroll 2
             for (int s = 0; s < STEPS; ++s) {
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
                         acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], bv, acc[k], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
     }
     const size_t wsize = (size_t)TAPS * A.Cin * A.Cout;

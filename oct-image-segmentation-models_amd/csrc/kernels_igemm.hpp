@@ -118,6 +118,7 @@ __device__ __forceinline__ void mfma_sweep(const float* __restrict__ Ws, const f
     };
     if constexpr (FULL) {
         float a0[MTW], b0[NTW], a1[MTW], b1[NTW];
+        __builtin_amdgcn_s_setprio(2);      // waves in their MFMA phase issue ahead of waves that are staging
         load(0, a0, b0);
 #pragma unroll
         for (int i = 0; i < STEPS; i += 2) {
@@ -126,6 +127,7 @@ __device__ __forceinline__ void mfma_sweep(const float* __restrict__ Ws, const f
             if (i + 2 < STEPS) load(i + 2, a0, b0);
             if (i + 1 < STEPS) fma(a1, b1);
         }
+        __builtin_amdgcn_s_setprio(0);
     } else {   // fewer channels than the chunk holds (tiny test configurations): plain runtime loop
         for (int tap = 0; tap < TAPS; ++tap)
             for (int ks = 0; ks < nks; ++ks) {
