@@ -98,6 +98,14 @@ int oct_unet_forward(oct_unet* h, const void* x_dev, int x_is_u8, int B, int tra
 /* After a forward with io.labels: out4_dev = {dice_loss_macro, dice_loss_micro,
  * dice_coef_macro, dice_coef_micro} (device floats). */
 int oct_unet_loss_dice(oct_unet* h, float smooth, float* out4_dev, oct_stream_t stream);
+/* focal_dice_loss (reference common/custom_losses.py:98-178, `SparseCategoricalFocalDiceLoss`):
+ *   L = w * mean_px[ cw[y] * (1 - p_y)^gamma * (-log p_y) ] + (1 - w) * dice_loss_{macro|micro}
+ * oct_unet_set_focal_dice selects it for the following forward / loss / backward calls (w = 0 restores the plain Dice
+ * losses; class_weight_dev = n_cls device floats or NULL, caller-owned and kept alive).  oct_unet_loss_focal_dice is
+ * oct_unet_loss_dice with 8 outputs: out8_dev = out4 + {focal term, w*focal + (1-w)*dice_macro,
+ * w*focal + (1-w)*dice_micro, 0}; oct_unet_backward then differentiates the combination chosen by its `macro` flag. */
+int oct_unet_set_focal_dice(oct_unet* h, float focal_loss_weight, float gamma, const float* class_weight_dev);
+int oct_unet_loss_focal_dice(oct_unet* h, float smooth, float* out8_dev, oct_stream_t stream);
 /* After training forward + loss_dice: fills the grads buffer with d(loss_scale*loss)/dparams. */
 int oct_unet_backward(oct_unet* h, const unsigned char* labels_dev, int macro, float loss_scale,
                       oct_stream_t stream);

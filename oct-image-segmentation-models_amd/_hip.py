@@ -61,6 +61,8 @@ SYMBOLS = [
     ("oct_unet_destroy", None, [C.c_void_p]),
     ("oct_unet_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _P(UNetIO), C.c_void_p]),
     ("oct_unet_loss_dice", C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    ("oct_unet_set_focal_dice", C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+    ("oct_unet_loss_focal_dice", C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     ("oct_unet_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     ("oct_adam_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_long, C.c_void_p]),

@@ -201,6 +201,8 @@ struct HeadBwdArgs {
     float* part;                         // [B*nblk][2*CIN]       BN-backward statistics
     float* wpart;                        // [B*nblk][CIN*C + C]   head kernel / bias gradient partials
     int HW, nblk, B, macro; float loss_scale; int act_bf16;
+    // focal_dice_loss: L = w * focal + (1 - w) * dice  (focal_w = 0: plain Dice)
+    float focal_w, focal_gamma; const float* focal_cw; float inv_count;   // inv_count = 1 / (B*H*W)
 };
 
 template <int C, int CIN, typename AT>
@@ -219,7 +221,8 @@ __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
         const double* k = A.macro ? A.bc + 2 * (b * C + c) : A.bc + 2 * A.B * C;
         num[c] = (float)k[0]; den[c] = (float)k[1];
     }
-    const float scale = A.macro ? A.loss_scale / (float)(A.B * C) : A.loss_scale;
+    const float scale = (1.f - A.focal_w) * (A.macro ? A.loss_scale / (float)(A.B * C) : A.loss_scale);
+    const float fscale = A.focal_w * A.loss_scale * A.inv_count;
 
     for (int chunk = blockIdx.x; chunk * kBlock < A.HW; chunk += gridDim.x) {
         const int px = chunk * kBlock + threadIdx.x;
@@ -233,6 +236,11 @@ __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
         for (int c = 0; c < C; ++c) {
             const float yv = lab == c ? 1.f : 0.f;
             dp[c] = -scale * (2.f * yv * den[c] - num[c]) / (den[c] * den[c]);
+            if (fscale != 0.f && lab == c && p[c] >= kFocalEps && p[c] <= 1.f - kFocalEps) {
+                // d/dp [ cw (1-p)^g (-log p) ] = cw ( g (1-p)^(g-1) log p - (1-p)^g / p ); zero where the clip is active
+                const float q = 1.f - p[c], cw = A.focal_cw ? A.focal_cw[c] : 1.f, qg1 = powf(q, A.focal_gamma - 1.f);
+                dp[c] += fscale * cw * (A.focal_gamma * qg1 * logf(p[c]) - qg1 * q / p[c]);
+            }
             dot = fmaf(p[c], dp[c], dot);
         }
         float dl[C];

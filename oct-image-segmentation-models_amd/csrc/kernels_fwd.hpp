@@ -273,9 +273,12 @@ struct HeadFwdArgs {
     const void* z; const float* ab;    // last conv's raw output (activation storage type) + BN record
     const float* w; const float* bias; // (CIN, C), (C)
     float* probs; unsigned char* argmax; const unsigned char* labels;
-    float* dice_part;                  // [B][nblk][DiceN]
+    float* dice_part;                  // [B][nblk][DiceN]; slot 5*C (always spare: 5*C < DiceN) = focal-loss sum
     int HW, nblk, act_bf16;
+    // focal half of focal_dice_loss (custom_losses.py:98-178): cw[y] * (1 - p_y)^gamma * (-log p_y), p clipped to [1e-7, 1-1e-7]
+    int focal_on; float focal_gamma; const float* focal_cw;   // class weights (C) or nullptr
 };
+constexpr float kFocalEps = 1e-7f;
 
 template <int C, int CIN, typename AT>
 __device__ inline void head_logits(const AT* __restrict__ zp, const float* __restrict__ ab,
@@ -339,6 +342,14 @@ __global__ __launch_bounds__(kBlock) void head_fwd_k(const HeadFwdArgs A) {
                     v[c * kDiceVals + 0] += yv * p[c]; v[c * kDiceVals + 1] += yv; v[c * kDiceVals + 2] += p[c];
                     v[c * kDiceVals + 3] += yv * ph;   v[c * kDiceVals + 4] += ph;
                 }
+                if (A.focal_on) {
+                    float py = p[0];
+#pragma unroll
+                    for (int c = 1; c < C; ++c) py = lab == c ? p[c] : py;
+                    py = fminf(fmaxf(py, kFocalEps), 1.f - kFocalEps);
+                    const float cw = A.focal_cw ? A.focal_cw[lab < C ? lab : 0] : 1.f;
+                    v[C * kDiceVals] += cw * powf(1.f - py, A.focal_gamma) * -logf(py);
+                }
             }
         }
     }
@@ -348,14 +359,18 @@ __global__ __launch_bounds__(kBlock) void head_fwd_k(const HeadFwdArgs A) {
 // Dice finalize: per-(b,c) sums in fp64 -> losses, metrics, and the per-(b,c) constants backward needs.
 //   out4 = {dice_loss_macro, dice_loss_micro, dice_coef_macro, dice_coef_micro}
 //   bc   = per (b,c): {Num = 2I+s, Den = T+P+s}; then the micro pair at [2*B*C], [2*B*C+1]
+//   out8 = out4 + {focal mean, w*focal + (1-w)*dice_macro, w*focal + (1-w)*dice_micro, 0}   (focal_dice_loss)
 struct DiceFinArgs {
     const float* part; int B, C, nblk, N;
     float smooth; float* out4; float* out4_user; double* bc;
+    int n_user;            // floats copied to out4_user: 4 (loss_dice) or 8 (loss_focal_dice)
+    double inv_count;      // 1 / (B*H*W)
+    float focal_w;
 };
 
 __global__ __launch_bounds__(kBlock) void dice_finalize_k(const DiceFinArgs A) {
-    __shared__ double sh[7][kBlock];
-    double acc[7] = {0, 0, 0, 0, 0, 0, 0};  // score_macro, coef_macro, I, T, P, Ih, Ph (micro sums)
+    __shared__ double sh[8][kBlock];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // score_macro, coef_macro, I, T, P, Ih, Ph (micro sums), focal sum
     const int n = A.B * A.C;
     for (int i = threadIdx.x; i < n; i += kBlock) {
         const int b = i / A.C, c = i % A.C;
@@ -370,23 +385,30 @@ __global__ __launch_bounds__(kBlock) void dice_finalize_k(const DiceFinArgs A) {
         acc[0] += num / den;
         acc[1] += (2.0 * v[3] + 1e-5) / (v[1] + v[4] + 1e-5);   // dice_coef_macro eps (custom_metrics.py:50)
         acc[2] += v[0]; acc[3] += v[1]; acc[4] += v[2]; acc[5] += v[3]; acc[6] += v[4];
+        if (c == 0)
+            for (int k = 0; k < A.nblk; ++k) acc[7] += A.part[((size_t)b * A.nblk + k) * A.N + A.C * kDiceVals];
     }
-    for (int j = 0; j < 7; ++j) sh[j][threadIdx.x] = acc[j];
+    for (int j = 0; j < 8; ++j) sh[j][threadIdx.x] = acc[j];
     __syncthreads();
     for (int o = kBlock / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) for (int j = 0; j < 7; ++j) sh[j][threadIdx.x] += sh[j][threadIdx.x + o];
+        if ((int)threadIdx.x < o) for (int j = 0; j < 8; ++j) sh[j][threadIdx.x] += sh[j][threadIdx.x + o];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         const double s = A.smooth;
         const double num = 2.0 * sh[2][0] + s, den = sh[3][0] + sh[4][0] + s;
         A.bc[2 * n] = num; A.bc[2 * n + 1] = den;
-        float o4[4];
+        float o4[8];
         o4[0] = (float)(1.0 - sh[0][0] / n);
         o4[1] = (float)(1.0 - num / den);
         o4[2] = (float)(sh[1][0] / n);
         o4[3] = (float)(2.0 * sh[5][0] / (sh[3][0] + sh[6][0]));  // no epsilon: 0/0 -> nan as the reference
-        for (int j = 0; j < 4; ++j) { A.out4[j] = o4[j]; if (A.out4_user) A.out4_user[j] = o4[j]; }
+        const double focal = sh[7][0] * A.inv_count, w = A.focal_w;
+        o4[4] = (float)focal;
+        o4[5] = (float)(w * focal + (1.0 - w) * (1.0 - sh[0][0] / n));
+        o4[6] = (float)(w * focal + (1.0 - w) * (1.0 - num / den));
+        o4[7] = 0.f;
+        for (int j = 0; j < 8; ++j) { A.out4[j] = o4[j]; if (A.out4_user && j < A.n_user) A.out4_user[j] = o4[j]; }
     }
 }
 

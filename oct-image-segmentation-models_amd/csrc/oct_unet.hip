@@ -190,7 +190,8 @@ struct oct_unet {
     std::vector<void*> pooled, gpooled;    // per encoder level (activation storage type)
     float* stat_part = nullptr;            // BN statistic partials (fwd and bwd share it: stream-ordered)
     ReduceAllArgs red{};                   // filled while backward runs; one reduce launch at the end
-    float* dice_part = nullptr; double* dice_bc = nullptr; float* loss4 = nullptr;
+    float* dice_part = nullptr; double* dice_bc = nullptr; float* loss4 = nullptr;   // loss4: 8 floats (dice_finalize_k)
+    float focal_w = 0.f, focal_gamma = 2.f; const float* focal_cw = nullptr;           // focal_dice_loss (0 = plain Dice)
     WtDesc* wt_descs = nullptr; int n_wt = 0; unsigned wt_total = 0;
     unsigned long long drop_step = 0; int drop_advance = 0;
     int last_B = 0; int last_training = 0; int have_dice = 0; int dice_final = 0;
@@ -235,7 +236,7 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
     float* sp = (float*)take(stat_max * 4);
     float* dp = (float*)take(B * nblk_head * 64 * 4);
     double* bc = (double*)take((B * 8 * 2 + 2) * 8);
-    float* l4 = (float*)take(4 * 4);
+    float* l4 = (float*)take(8 * 4);
     WtDesc* wd = c.training ? (WtDesc*)take(pl.L.size() * sizeof(WtDesc)) : nullptr;
     if (h) h->wt_descs = wd;
     if (h) { h->stat_part = sp; h->dice_part = dp; h->dice_bc = bc; h->loss4 = l4; }
@@ -540,6 +541,7 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
     a.z = last.z; a.ab = last.bn; a.w = h->params + hd.w_off; a.bias = h->params + hd.b_off;
     a.probs = io ? io->probs : nullptr; a.argmax = io ? io->argmax : nullptr; a.labels = io ? io->labels : nullptr;
     a.dice_part = h->dice_part; a.HW = hd.H * hd.W; a.nblk = head_nblk(a.HW, B); a.act_bf16 = h->cfg.dtype;
+    a.focal_on = h->focal_w > 0.f; a.focal_gamma = h->focal_gamma; a.focal_cw = h->focal_cw;
     const int rc = DISPATCH_C(launch_head_fwd, h->cfg.n_cls, a, hd.cin, B, s);
     if (rc) return rc;
     h->last_B = B; h->last_training = training; h->have_dice = a.labels != nullptr;
@@ -663,6 +665,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     hb.z = last.z; hb.bn = last.bn; hb.w = h->params + hd.w_off; hb.bias = h->params + hd.b_off;
     hb.labels = labels; hb.bc = h->dice_bc; hb.g = last.g; hb.part = h->stat_part; hb.wpart = hd.dwp;
     hb.HW = hd.H * hd.W; hb.nblk = head_nblk(hb.HW, B); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale; hb.act_bf16 = h->cfg.dtype;
+    hb.focal_w = h->focal_w; hb.focal_gamma = h->focal_gamma; hb.focal_cw = h->focal_cw; hb.inv_count = 1.f / ((float)B * hb.HW);
     {   // backward-data weights of every block for this step's parameters (one launch)
         ProfScope ps(s, "prep_wt_k", "all", 0, (double)h->wt_total * 8);
         prep_wt_k<<<std::min<unsigned>((h->wt_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wt_descs, h->n_wt, h->wt_total);
@@ -868,6 +871,27 @@ int oct_unet_loss_dice(oct_unet* h, float smooth, float* out4, oct_stream_t stre
     DiceFinArgs a{};
     a.part = h->dice_part; a.B = h->last_B; a.C = h->cfg.n_cls; a.nblk = head_nblk(h->cfg.H * h->cfg.W, h->last_B);
     a.N = dice_n(a.C); a.smooth = smooth; a.out4 = h->loss4; a.out4_user = out4; a.bc = h->dice_bc;
+    a.n_user = 4; a.inv_count = 1.0 / ((double)h->last_B * h->cfg.H * h->cfg.W); a.focal_w = h->focal_w;
+    dice_finalize_k<<<1, kBlock, 0, (hipStream_t)stream>>>(a);
+    HIP_OK(hipGetLastError());
+    h->dice_final = 1;
+    return 0;
+}
+
+int oct_unet_set_focal_dice(oct_unet* h, float focal_loss_weight, float gamma, const float* class_weight_dev) {
+    if (!h) return fail(-1, "null handle");
+    if (!(focal_loss_weight >= 0.f && focal_loss_weight <= 1.f) || !(gamma >= 0.f)) return fail(-1, "focal_dice: weight must be in [0,1], gamma >= 0");
+    h->focal_w = focal_loss_weight; h->focal_gamma = gamma; h->focal_cw = class_weight_dev;
+    return 0;
+}
+
+int oct_unet_loss_focal_dice(oct_unet* h, float smooth, float* out8, oct_stream_t stream) {
+    if (!h) return fail(-1, "null handle");
+    if (!h->have_dice) return fail(-1, "loss_focal_dice needs a preceding forward with io.labels");
+    DiceFinArgs a{};
+    a.part = h->dice_part; a.B = h->last_B; a.C = h->cfg.n_cls; a.nblk = head_nblk(h->cfg.H * h->cfg.W, h->last_B);
+    a.N = dice_n(a.C); a.smooth = smooth; a.out4 = h->loss4; a.out4_user = out8; a.bc = h->dice_bc;
+    a.n_user = 8; a.inv_count = 1.0 / ((double)h->last_B * h->cfg.H * h->cfg.W); a.focal_w = h->focal_w;
     dice_finalize_k<<<1, kBlock, 0, (hipStream_t)stream>>>(a);
     HIP_OK(hipGetLastError());
     h->dice_final = 1;

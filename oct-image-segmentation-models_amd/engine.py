@@ -172,6 +172,27 @@ class UNetEngine:
             _hip.check(_hip.lib().oct_unet_loss_dice(self._h, smooth, out.data_ptr(), self._stream()), "oct_unet_loss_dice")
         return out
 
+    def set_focal_dice(self, focal_loss_weight: float = 0.5, gamma: float = 2.0, class_weight=None) -> None:
+        """Select ``focal_dice_loss`` (reference custom_losses.py:98-178) for the following forward / loss / backward
+        calls: L = w*focal + (1-w)*dice.  ``focal_loss_weight = 0`` restores the plain Dice losses."""
+        cw = None
+        if class_weight is not None:
+            cw = torch.as_tensor(np.asarray(class_weight, np.float32), device=self.device).contiguous()
+            if cw.numel() != self.cfg.n_cls:
+                raise OctError(f"class_weight must have {self.cfg.n_cls} entries")
+        self._focal_cw = cw          # keep the device buffer alive: the library only stores the pointer
+        self._focal_active = float(focal_loss_weight) > 0.0
+        with torch.cuda.device(self.device):
+            _hip.check(_hip.lib().oct_unet_set_focal_dice(self._h, float(focal_loss_weight), float(gamma),
+                                                          cw.data_ptr() if cw is not None else None), "oct_unet_set_focal_dice")
+
+    def loss_focal_dice(self, smooth: float = 1e-5) -> torch.Tensor:
+        """loss_dice() + [focal term, w*focal+(1-w)*dice_macro, w*focal+(1-w)*dice_micro, 0] (device tensor, 8 floats)."""
+        out = torch.empty(8, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _hip.check(_hip.lib().oct_unet_loss_focal_dice(self._h, smooth, out.data_ptr(), self._stream()), "oct_unet_loss_focal_dice")
+        return out
+
     def backward(self, labels: torch.Tensor, macro: bool = True, loss_scale: float = 1.0):
         self._check_labels(labels, labels.shape[0])
         with torch.cuda.device(self.device):

@@ -156,9 +156,10 @@ class Model:
     # ---- keras.Model surface -------------------------------------------------------------------------
     def compile(self, optimizer=None, loss=None, metrics=None, **kwargs):
         loss_name = getattr(loss, "oct_loss", None) if loss is not None else None
-        if loss is not None and loss_name not in ("dice_loss_macro", "dice_loss_micro"):
-            raise OctError("compile(loss=...): only the Dice losses from common.custom_losses are implemented by "
-                           "the HIP engine (the loss arithmetic is fused into the head kernel)")
+        if loss is not None and loss_name not in ("dice_loss_macro", "dice_loss_micro", "focal_dice_loss"):
+            raise OctError("compile(loss=...): only the Dice losses and focal_dice_loss from common.custom_losses are "
+                           "implemented by the HIP engine (the loss arithmetic is fused into the head kernels)")
+        self._focal = dict(getattr(loss, "oct_focal", None) or {}) if loss_name == "focal_dice_loss" else None
         metric_name = None
         for m in metrics or []:
             metric_name = getattr(m, "oct_metric", None)
@@ -253,14 +254,19 @@ class Model:
         return x, l
 
     def _run_epoch(self, seq, training: bool, rank: int, world: int):
-        macro = self._loss_name != "dice_loss_micro"
+        focal = getattr(self, "_focal", None)
+        macro = focal["dice_macro"] if focal else self._loss_name != "dice_loss_micro"
         acc = None
         n = len(seq)
         for i in range(n):
             x, lab = self._device_batch(seq, i, rank, world)
             eng = self._ensure_engine(x.shape[0], training)
+            if focal:      # (re)selected per batch: _ensure_engine may have built a new engine
+                eng.set_focal_dice(focal["focal_loss_weight"], focal["gamma"], focal["class_weight"])
+            elif getattr(eng, "_focal_active", False):
+                eng.set_focal_dice(0.0)     # an engine last used by a focal model goes back to the plain Dice losses
             eng.forward(x, training=training, labels=lab, want_probs=False)
-            loss4 = eng.loss_dice()
+            loss4 = eng.loss_focal_dice() if focal else eng.loss_dice()
             if training:
                 eng.backward(lab, macro=macro, loss_scale=1.0 / world)
                 parallel.allreduce_gradients(eng.grads)
@@ -272,7 +278,7 @@ class Model:
         if world > 1:
             torch.distributed.all_reduce(acc); acc /= world
         v = acc.cpu().numpy()
-        out = {"loss": float(v[0] if macro else v[1])}
+        out = {"loss": float((v[5] if macro else v[6]) if focal else (v[0] if macro else v[1]))}
         if self._metric_name:
             out[self._metric_name] = float(v[2] if self._metric_name == "dice_coef_macro" else v[3])
         return out

@@ -297,6 +297,41 @@ def dice_loss_grad(y, p, macro: bool, smooth=1e-5):
     return -(2.0 * y * D - (2.0 * I + smooth)) / (D * D)
 
 
+FOCAL_EPS = 1e-7   # keras backend epsilon: the probabilities are clipped to [eps, 1 - eps] before the logarithm
+
+
+def focal_loss_mean(labels, p, gamma=2.0, class_weight=None):
+    """Focal half of ``SparseCategoricalFocalDiceLoss.call`` (custom_losses.py:98-160): the per-pixel sparse
+    categorical focal loss  cw[y] * (1 - p_y)^gamma * (-log p_y)  of the third-party ``focal-loss==0.0.7``
+    (``SparseCategoricalFocalLoss``, probabilities clipped to [eps, 1-eps]) summed and divided by the number of label
+    elements, custom_losses.py:150-153.  PARITY UNPINNED (third-party package absent; published formula restated)."""
+    lab = np.asarray(labels).reshape(p.shape[:-1]).astype(np.int64)
+    py = np.clip(np.take_along_axis(p, lab[..., None], axis=-1)[..., 0], FOCAL_EPS, 1.0 - FOCAL_EPS)
+    w = 1.0 if class_weight is None else np.asarray(class_weight, p.dtype)[lab]
+    return float((w * (1.0 - py) ** gamma * -np.log(py)).sum() / lab.size)
+
+
+def focal_loss_grad(labels, p, gamma=2.0, class_weight=None):
+    """d focal_loss_mean / d p (non-zero only at the true class; zero where the clip is active)."""
+    lab = np.asarray(labels).reshape(p.shape[:-1]).astype(np.int64)
+    raw = np.take_along_axis(p, lab[..., None], axis=-1)[..., 0]
+    py = np.clip(raw, FOCAL_EPS, 1.0 - FOCAL_EPS)
+    w = 1.0 if class_weight is None else np.asarray(class_weight, p.dtype)[lab]
+    d = w * (gamma * (1.0 - py) ** (gamma - 1.0) * np.log(py) - (1.0 - py) ** gamma / py) / lab.size
+    d = np.where((raw >= FOCAL_EPS) & (raw <= 1.0 - FOCAL_EPS), d, 0.0)
+    g = np.zeros_like(p)
+    np.put_along_axis(g, lab[..., None], d[..., None], axis=-1)
+    return g
+
+
+def focal_dice_loss(labels, p, num_classes, gamma=2.0, class_weight=None, focal_loss_weight=0.5, dice_macro=True,
+                    smooth=1e-5):
+    """``focal_dice_loss`` (custom_losses.py:163-178):  w * focal + (1 - w) * dice."""
+    y = one_hot(labels, num_classes, p.dtype)
+    dice = dice_loss_macro(y, p, smooth) if dice_macro else dice_loss_micro(y, p, smooth)
+    return focal_loss_weight * focal_loss_mean(labels, p, gamma, class_weight) + (1.0 - focal_loss_weight) * dice
+
+
 def dice_coef_macro(y, p, eps=1e-5):
     """Training monitor, custom_metrics.py:48-77: hard threshold p>0.5."""
     ph = (p > 0.5).astype(p.dtype)
@@ -464,14 +499,19 @@ def _maxpool_backward(x, g):
 
 
 def backward(cfg: UNetConfig, params, cache, labels: np.ndarray, macro: bool = True,
-             smooth: float = 1e-5, loss_scale: float = 1.0):
-    """Hand-derived reverse pass of ``forward(training=True)`` for the Dice losses.
+             smooth: float = 1e-5, loss_scale: float = 1.0, focal=None):
+    """Hand-derived reverse pass of ``forward(training=True)`` for the Dice losses, or -- with
+    ``focal = (focal_loss_weight, gamma, class_weight or None)`` -- for ``focal_dice_loss``.
     Returns (loss, grads) with grads in the same structure as ``params``."""
     plan = build_plan(cfg)
     probs = cache[-1]["probs"]
     y = one_hot(labels, cfg.num_classes, probs.dtype)
     loss = dice_loss_macro(y, probs, smooth) if macro else dice_loss_micro(y, probs, smooth)
     dp = dice_loss_grad(y, probs, macro, smooth) * loss_scale
+    if focal is not None:
+        fw, gamma, cw = focal
+        loss = fw * focal_loss_mean(labels, probs, gamma, cw) + (1.0 - fw) * loss
+        dp = (1.0 - fw) * dp + fw * loss_scale * focal_loss_grad(labels, probs, gamma, cw)
     dz = probs * (dp - (probs * dp).sum(axis=-1, keepdims=True))  # softmax Jacobian
     grads: List[dict] = [dict() for _ in plan]
     g_out: Dict[int, np.ndarray] = {}  # gradient wrt the (activated) output of conv li

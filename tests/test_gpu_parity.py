@@ -379,6 +379,55 @@ def test_full_size_parity_with_real_kernel_selection():
     assert abs(fd - gv) < 0.03 * abs(gv), (fd, gv)
 
 
+@pytest.mark.parametrize("macro", [True, False])
+@pytest.mark.parametrize("cw", [None, (0.5, 2.0, 1.25)])
+def test_focal_dice_loss_and_gradients_match_oracle(macro, cw):
+    """focal_dice_loss (reference custom_losses.py:98-178; third-party focal-loss formula restated -- parity unpinned):
+    loss terms and every gradient tensor vs the fp64 oracle, with and without class weights."""
+    case = CASES[0]
+    B, H, W, C, sn, P, L, ic = case
+    fw, gamma = 0.35, 2.0
+    cfg, eng, p64, s64 = make(B, H, W, C, sn, P, L, ic, training=True)
+    images, labels = data(B, H, W, C, ic, seed=MARGIN_SEED[case])
+    x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+    eng.set_dropout_step(DROP_STEP)
+    mask = eng.dropout_mask(B).cpu().numpy().astype(np.float64)
+    eng.set_focal_dice(fw, gamma, cw)
+    probs, _ = eng.forward(x, training=True, labels=lab)
+    v = eng.loss_focal_dice().cpu().numpy()
+    eng.backward(lab, macro=macro, loss_scale=0.5)
+    ref, cache = on.forward(cfg, p64, s64, on.preprocess_u8(images, np.float64), training=True, dropout_mask=mask)
+    assert relu_margin(cfg, p64, cache) > 2e-5
+    assert np.abs(probs.cpu().numpy() - ref).max() < PROB_TOL
+    y = on.one_hot(labels, C, np.float64)
+    focal = on.focal_loss_mean(labels, ref, gamma, cw)
+    assert abs(v[0] - on.dice_loss_macro(y, ref)) < 1e-5 and abs(v[1] - on.dice_loss_micro(y, ref)) < 1e-5
+    assert abs(v[4] - focal) < 1e-5 * max(1.0, focal)
+    assert abs(v[5] - on.focal_dice_loss(labels, ref, C, gamma, cw, fw, True)) < 1e-5
+    assert abs(v[6] - on.focal_dice_loss(labels, ref, C, gamma, cw, fw, False)) < 1e-5
+    loss, grads = on.backward(cfg, p64, cache, labels, macro=macro, loss_scale=0.5, focal=(fw, gamma, cw))
+    g = eng.grads.cpu().numpy()
+    for L_, gr in zip(eng.layers, grads):
+        n = L_["kh"] * L_["kw"] * L_["cin"] * L_["cout"]; c = L_["cout"]
+        pieces = [("kernel", L_["kernel_off"], n), ("bias", L_["bias_off"], c)]
+        if L_["has_bn"]:
+            pieces += [("gamma", L_["gamma_off"], c), ("beta", L_["beta_off"], c)]
+        kscale = np.abs(gr["kernel"]).max()
+        for key, off, cnt in pieces:
+            refv = gr[key].ravel()
+            scale = max(np.abs(refv).max(), kscale if key == "bias" else 0.0, 1e-12)
+            assert np.abs(g[off:off + cnt] - refv).max() / scale < GRAD_RTOL, f"{L_['name']}.{key}"
+    # w = 0 restores the plain Dice gradient bit for bit
+    eng.set_focal_dice(0.0)
+    eng.set_dropout_step(DROP_STEP)          # same dropout mask as the fresh engine below
+    eng.forward(x, training=True, labels=lab); eng.loss_dice(); eng.backward(lab, macro=macro, loss_scale=0.5)
+    g0 = eng.grads.clone()
+    cfg2, eng2, _, _ = make(B, H, W, C, sn, P, L, ic, training=True)
+    eng2.set_dropout_step(DROP_STEP)
+    eng2.forward(x, training=True, labels=lab); eng2.loss_dice(); eng2.backward(lab, macro=macro, loss_scale=0.5)
+    assert torch.equal(g0, eng2.grads)
+
+
 # ---- bf16 activation storage (BASELINE configs[2]: "bf16 with fp32 BN accum") ---------------------------------
 # dtype=1 keeps every activation / activation-gradient tensor in HBM as bf16 (round-to-nearest-even at the store),
 # while arithmetic, BN statistics, parameters and parameter gradients stay fp32.  Two kinds of gate:

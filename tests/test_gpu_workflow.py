@@ -117,3 +117,23 @@ def test_resume_from_initial_model(trained, tmp_path):
                         loss="dice_loss_micro", metric="dice_coef_micro", epochs=2, batch_size=4, early_stopping=False)
     r2 = train(tp, None)
     assert r2.history["val_dice_coef_micro"][0] > 0.45      # starts from the trained weights, not from scratch
+
+
+def test_train_model_with_focal_dice_loss(tmp_path):
+    """Registry name ``focal_dice_loss`` (sparse labels, loss_fn_kwargs as in the reference) trains through train_model."""
+    from oct_image_segmentation_models_amd import optimizers
+    from oct_image_segmentation_models_amd.common import h5io
+    from oct_image_segmentation_models_amd.training.training import train_model
+    from oct_image_segmentation_models_amd.training.training_parameters import TrainingParams
+    tr_i, tr_l = on.synth_scans(8, 32, 64, 3, seed=11)
+    va_i, va_l = on.synth_scans(4, 32, 64, 3, seed=12)
+    h5io.save(tmp_path / "data.hdf5", {"train_images": tr_i, "train_labels": tr_l, "val_images": va_i, "val_labels": va_l})
+    tp = TrainingParams(model_architecture="unet", training_dataset_path=tmp_path / "data.hdf5", initial_model=None,
+                        results_location=tmp_path / "results", opt_con=optimizers.Adam, opt_params={"learning_rate": 4e-3},
+                        loss="focal_dice_loss", loss_fn_kwargs={"gamma": 2.0, "focal_loss_weight": 0.4, "class_weight": [1.0, 2.0, 1.0]},
+                        metric="dice_coef_macro", epochs=25, batch_size=4, model_hyperparameters={"pool_layers": 2},
+                        patience=26, seed=3)
+    res = train_model(tp, None)
+    h = res.history
+    assert len(h["loss"]) == 25 and np.isfinite(h["loss"]).all() and np.isfinite(h["val_loss"]).all()
+    assert h["loss"][-1] < 0.7 * h["loss"][0]

@@ -228,3 +228,25 @@ def test_overall_aggregation_matches_numpy_definition(tmp_path):
     assert np.allclose(out["median_errors"], np.nanmedian(np.nanmean(errs, axis=2), axis=0))
     txt = open(tmp_path / ev.OVERALL_EVALUATION_RESULTS_FILENAME_CSV).read().splitlines()
     assert txt[0].startswith("Mean dice_coef_classes,") and any(l.startswith("SD errors,") for l in txt)
+
+
+def test_focal_dice_loss_factory_matches_oracle_and_compiles():
+    """Registry entry ``focal_dice_loss`` (reference custom_losses.py:163-178, sparse labels) vs the oracle."""
+    from oracle import unet_numpy as on
+    from oct_image_segmentation_models_amd.common import custom_losses
+    from oct_image_segmentation_models_amd.models.engine_model import Model
+    entry = custom_losses.custom_loss_objects["focal_dice_loss"]
+    assert entry["takes_sparse"] is True
+    rng = np.random.default_rng(0)
+    z = rng.normal(size=(2, 6, 7, 4)); p = np.exp(z) / np.exp(z).sum(-1, keepdims=True)
+    lab = rng.integers(0, 4, (2, 6, 7, 1)).astype(np.uint8)
+    for kw in (dict(), dict(gamma=1.5, class_weight=[1, 2, 3, 4], focal_loss_weight=0.2, dice_macro=False)):
+        fn = entry["function"](num_classes=4, is_y_true_sparse=True, **kw)
+        ref = on.focal_dice_loss(lab, p, 4, kw.get("gamma", 2), kw.get("class_weight"), kw.get("focal_loss_weight", 0.5),
+                                 kw.get("dice_macro", True))
+        assert abs(fn(lab, p) - ref) < 1e-12
+        m = Model("unet", dict(input_channels=1, num_classes=4, image_height=16, image_width=32))
+        m.compile(optimizer=None, loss=fn, metrics=[])
+        assert m._loss_name == "focal_dice_loss" and m._focal["dice_macro"] == kw.get("dice_macro", True)
+    with pytest.raises(ValueError):
+        entry["function"](num_classes=4, class_weight=[1, 2])

@@ -185,3 +185,31 @@ def test_oracle_reproduces_committed_golden():
     _, grads = on.backward(cfg, params, cache, G["labels"], macro=True)
     assert np.abs(on.flatten_grads(grads) - G["grads_macro"]).max() < 1e-13
     assert np.abs(on.flatten_state(on.updated_moving_stats(cfg, state, cache)) - G["state_after"]).max() < 1e-13
+
+
+def test_focal_dice_loss_known_answer_and_gradient():
+    """focal_dice_loss (custom_losses.py:98-178): hand-computed value on a 2-pixel case, gradient vs finite
+    differences and vs torch autograd of the same formula."""
+    import torch
+    p = np.array([[[[0.7, 0.2, 0.1], [0.25, 0.5, 0.25]]]], np.float64)       # (1,1,2,3)
+    lab = np.array([[[[0], [2]]]], np.uint8)
+    cw = np.array([1.0, 2.0, 3.0])
+    f = (1.0 * 0.3 ** 2 * -np.log(0.7) + 3.0 * 0.75 ** 2 * -np.log(0.25)) / 2
+    assert abs(on.focal_loss_mean(lab, p, 2.0, cw) - f) < 1e-12
+    y = on.one_hot(lab, 3, np.float64)
+    assert abs(on.focal_dice_loss(lab, p, 3, 2.0, cw, 0.3, True) - (0.3 * f + 0.7 * on.dice_loss_macro(y, p))) < 1e-12
+    rng = np.random.default_rng(0)
+    z = rng.normal(size=(2, 4, 5, 3)); p = np.exp(z) / np.exp(z).sum(-1, keepdims=True)
+    lab = rng.integers(0, 3, (2, 4, 5, 1)).astype(np.uint8)
+    for gamma, w in ((2.0, cw), (1.5, None)):
+        g = on.focal_loss_grad(lab, p, gamma, w)
+        for idx in [(0, 1, 2, int(lab[0, 1, 2, 0])), (1, 3, 4, int(lab[1, 3, 4, 0])), (1, 0, 0, (int(lab[1, 0, 0, 0]) + 1) % 3)]:
+            q = p.copy(); q[idx] += 1e-6; r = p.copy(); r[idx] -= 1e-6
+            fd = (on.focal_loss_mean(lab, q, gamma, w) - on.focal_loss_mean(lab, r, gamma, w)) / 2e-6
+            assert abs(fd - g[idx]) < 1e-6 * max(1.0, abs(fd))
+        tp = torch.tensor(p, requires_grad=True)
+        tl = torch.tensor(lab[..., 0].astype(np.int64))
+        py = tp.gather(-1, tl[..., None])[..., 0].clamp(1e-7, 1 - 1e-7)
+        tw = torch.ones_like(py) if w is None else torch.tensor(w)[tl]
+        (tw * (1 - py) ** gamma * -py.log()).sum().div(tl.numel()).backward()
+        assert np.abs(tp.grad.numpy() - g).max() < 1e-12
