@@ -316,6 +316,12 @@ __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // lane bases of the MFMA operands (lane = (i, kk): row/column i of the 32-tile, pixel kk of the pair)
+    const float* xb[UPW];
+#pragma unroll
+    for (int k = 0; k < UPW; ++k)
+        xb[k] = Xs + (UP ? ((kk + ukx[k]) >> 1) : uky[k] * IW + ukx[k] + kk) * CIC + umt[k] * 32 + i;
+    const float* const db = Ds + kk * COC + i;
 
     TileStager<CIC, COC, IH, IW, UP, KH, TH, AT> st;
     auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
@@ -337,32 +343,34 @@ __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
             tile_of(tl + A.npb, nb, ny0, nx0);
             st.load(A, nb, ny0, nx0, ci0, co0);
         }
-        {   // TH rows x 16 k-steps; the operands of step s+1 are read from LDS while the MFMAs of step s issue
-            constexpr int STEPS = TH * (TW / 2);
-            auto load = [&](int s, float (&a)[UPW], float& bv) {
-                const int rr = s / (TW / 2), p = 2 * (s % (TW / 2)) + kk;
-                bv = Ds[(rr * TW + p) * COC + i];
-#pragma unroll
-                for (int k = 0; k < UPW; ++k) {
-                    int off;
-                    if constexpr (UP) off = (((rr + uky[k]) >> 1) * IW + ((p + ukx[k]) >> 1)) * CIC + umt[k] * 32 + i;
-                    else off = ((rr + uky[k]) * IW + p + ukx[k]) * CIC + umt[k] * 32 + i;
-                    a[k] = Xs[off];   // the (possibly absent) last unit of a wave reads a clamped, valid address
-                }
-            };
-            float an[UPW], bn;
+        {   // TH rows x 16 pixel pairs.  Every operand address is (per-unit lane base, set up once) + (row offset,
+            // scalar) + (pair offset, an immediate of the unrolled pair loop): no per-step index arithmetic; the
+            // operands of pair pp+1 are read from LDS while the MFMAs of pair pp issue.
             __builtin_amdgcn_s_setprio(2);
-            load(0, an, bn);
-#pragma unroll 2
-            for (int s = 0; s < STEPS; ++s) {
-                float a[UPW]; const float bv = bn;
+#pragma unroll 1
+            for (int rr = 0; rr < TH; ++rr) {
+                const float* dbr = db + rr * TW * COC;
+                const float* xr[UPW];
 #pragma unroll
-                for (int k = 0; k < UPW; ++k) a[k] = an[k];
-                if (s + 1 < STEPS) load(s + 1, an, bn);
+                for (int k = 0; k < UPW; ++k) xr[k] = xb[k] + (UP ? ((rr + uky[k]) >> 1) : rr) * (IW * CIC);
+                auto load = [&](int pp, float (&a)[UPW], float& bv) {
+                    bv = dbr[2 * pp * COC];
 #pragma unroll
-                for (int k = 0; k < UPW; ++k) {
-                    if (4 * k + 3 < UNITS || wave + 4 * k < UNITS)   // compile-time true except for the last unit
-                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], bv, acc[k], 0, 0, 0);
+                    for (int k = 0; k < UPW; ++k) a[k] = xr[k][(UP ? pp : 2 * pp) * CIC];
+                };
+                float an[UPW], bn;
+                load(0, an, bn);
+#pragma unroll
+                for (int pp = 0; pp < TW / 2; ++pp) {
+                    float a[UPW]; const float bv = bn;
+#pragma unroll
+                    for (int k = 0; k < UPW; ++k) a[k] = an[k];
+                    if (pp + 1 < TW / 2) load(pp + 1, an, bn);
+#pragma unroll
+                    for (int k = 0; k < UPW; ++k) {
+                        if (4 * k + 3 < UNITS || wave + 4 * k < UNITS)   // compile-time true except for the last unit
+                            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], bv, acc[k], 0, 0, 0);
+                    }
                 }
             }
             __builtin_amdgcn_s_setprio(0);
