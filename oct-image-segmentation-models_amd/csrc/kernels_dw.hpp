@@ -158,23 +158,37 @@ __global__ __launch_bounds__(kBlock) void conv_dw16_k(const ConvBwdWArgs A) {
             tile_of(tl + A.npb, nb, ny0, nx0);
             st.load(A, nb, ny0, nx0, ci0, co0);
         }
+        // operand address = lane base (once per tile) + row offset + an immediate of the unrolled k-step loop;
+        // the operands of step ks+1 are read while the MFMAs of step ks issue
+        __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int rs = 0; rs < 2; ++rs) {
             const int rr = wave + 4 * rs;
-#pragma unroll 2
-            for (int ks = 0; ks < TW / 4; ++ks) {
-                const int p = 4 * ks + kk;
-                const float bv = Ds[(rr * TW + p) * 16 + i];
+            const float* dbr = Ds + (rr * TW + kk) * 16 + i;
+            const float* xr[MTILES];
 #pragma unroll
-                for (int mt = 0; mt < MTILES; ++mt) {
-                    int off;
-                    if constexpr (UP) off = (((rr + aky[mt]) >> 1) * IW + ((p + akx[mt]) >> 1)) * CIC + aci[mt];
-                    else off = aoff[mt] + (rr * IW + p) * CIC;
-                    const float a = aval[mt] ? Xs[off] : 0.f;
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[mt], 0, 0, 0);
-                }
+            for (int mt = 0; mt < MTILES; ++mt) {
+                if constexpr (UP) xr[mt] = Xs + (((rr + aky[mt]) >> 1) * IW + ((kk + akx[mt]) >> 1)) * CIC + aci[mt];
+                else xr[mt] = Xs + aoff[mt] + (rr * IW + kk) * CIC;
+            }
+            auto load = [&](int ks, float (&a)[MTILES], float& bv) {
+                bv = dbr[4 * ks * 16];
+#pragma unroll
+                for (int mt = 0; mt < MTILES; ++mt) a[mt] = xr[mt][(UP ? 2 * ks : 4 * ks) * CIC];
+            };
+            float an[MTILES], bn;
+            load(0, an, bn);
+#pragma unroll
+            for (int ks = 0; ks < TW / 4; ++ks) {
+                float a[MTILES]; const float bv = bn;
+#pragma unroll
+                for (int mt = 0; mt < MTILES; ++mt) a[mt] = aval[mt] ? an[mt] : 0.f;
+                if (ks + 1 < TW / 4) load(ks + 1, an, bn);
+#pragma unroll
+                for (int mt = 0; mt < MTILES; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv, acc[mt], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     // ---- 4-wave sum through LDS, then the slab ----
     __syncthreads();
@@ -254,19 +268,33 @@ __global__ __launch_bounds__(kBlock) void conv_dwpair8_k(const ConvBwdWArgs A) {
             tile_of(tl + A.npb, nb, ny0, nx0);
             st.load(A, nb, ny0, nx0, ci0, 0);
         }
+        // lane's K slot = pixel pair n = 4 ks + kk; address = lane base + row offset + an immediate of the unrolled loop
+        __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int rs = 0; rs < 2; ++rs) {
             const int rr = wave + 4 * rs;
-#pragma unroll 2
-            for (int ks = 0; ks < TW / 8; ++ks) {
-                const int n = 4 * ks + kk;                  // pixel pair of this lane's K slot
-                const float bv = Ds[(rr * TW + 2 * n) * 8 + i];                 // i = (j, co): pixel 2n + j, channel co
-                const float* xa = Xs + (rr * IW + 2 * n) * XST;
+            const float* dbr = Ds + (rr * TW + 2 * kk) * 8 + i;               // i = (j, co): pixel 2n + j, channel co
+            const float* xr[MTILES];
 #pragma unroll
-                for (int mt = 0; mt < MTILES; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[aoff[mt]], bv, acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MTILES; ++mt) xr[mt] = Xs + (rr * IW + 2 * kk) * XST + aoff[mt];
+            auto load = [&](int ks, float (&a)[MTILES], float& bv) {
+                bv = dbr[8 * ks * 8];
+#pragma unroll
+                for (int mt = 0; mt < MTILES; ++mt) a[mt] = xr[mt][8 * ks * XST];
+            };
+            float an[MTILES], bn;
+            load(0, an, bn);
+#pragma unroll
+            for (int ks = 0; ks < TW / 8; ++ks) {
+                float a[MTILES]; const float bv = bn;
+#pragma unroll
+                for (int mt = 0; mt < MTILES; ++mt) a[mt] = an[mt];
+                if (ks + 1 < TW / 8) load(ks + 1, an, bn);
+#pragma unroll
+                for (int mt = 0; mt < MTILES; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv, acc[mt], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     // ---- 4-wave sum through LDS into D[m][16], then fold the two pixel parities into the 3x3 taps ----
     __syncthreads();
