@@ -14,82 +14,92 @@ namespace oct {
 // ---- software-pipelined staging: the global loads of tile t+1 are issued (into registers) before the MFMA loop of
 // tile t and written to LDS (with the consumer-side transform) after it, so HBM/L2 latency hides under compute ----
 
-// address part of the logical-input fetch: pointer to 4 consecutive channels (concat aware)
-template <typename AT>
-__device__ __forceinline__ const AT* x4_ptr(const ConvBwdWArgs& A, size_t pix, int c) {
-    if ((A.flags & F_TWO) && c >= A.C0) return reinterpret_cast<const AT*>(A.x1) + pix * A.C1 + (c - A.C0);
-    return reinterpret_cast<const AT*>(A.x0) + pix * A.C0 + c;
-}
-// transform part: BN+ReLU affine and dropout of the 4 loaded channels
-__device__ __forceinline__ float4 x4_xform(const ConvBwdWArgs& A, float4 v, size_t pix, int c) {
-    const float* ab = A.ab0; int C = A.C0, cc = c;
-    if ((A.flags & F_TWO) && c >= A.C0) { ab = A.ab1; C = A.C1; cc = c - A.C0; }
-    if (A.flags & F_AFF) {
-        const float4 a = ld4(ab + cc), bb = ld4(ab + C + cc);
-        v.x = fmaxf(fmaf(a.x, v.x, bb.x), 0.f); v.y = fmaxf(fmaf(a.y, v.y, bb.y), 0.f);
-        v.z = fmaxf(fmaf(a.z, v.z, bb.z), 0.f); v.w = fmaxf(fmaf(a.w, v.w, bb.w), 0.f);
-    }
-    if (A.flags & F_DROP) {
-        const uint32_t el = (uint32_t)(pix * C + cc);
-        v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
-        v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
-    }
-    return v;
-}
-
+// Per-thread invariants are set up ONCE (init): a thread always serves the same channel quad of X and of dz (kBlock
+// is a multiple of CIC/4 and COC/4), so its source tensor (concat aware), BN affine and LDS column never change; per
+// slot only the packed local pixel (ly, lx) is kept.  Per tile: one wave-uniform base pointer, and interior tiles skip
+// every bounds test.
 template <int CIC, int COC, int IH, int IW, bool UP, int KH, int TH, typename AT, int XSTRIDE = CIC>
 struct TileStager {
-    static constexpr int NX = (IH * IW * (CIC / 4) + kBlock - 1) / kBlock;   // float4 per thread, X tile
-    static constexpr int ND = (TH * 32 * (COC / 4) + kBlock - 1) / kBlock;   // float4 per thread, dz tile
+    static constexpr int QX = CIC / 4, PPX = kBlock / QX, NPX = IH * IW, NX = (NPX + PPX - 1) / PPX;   // X tile
+    static constexpr int QD = COC / 4, PPD = kBlock / QD, NPD = TH * 32, ND = (NPD + PPD - 1) / PPD;   // dz tile
     float4 xr[NX], dr[ND];
+    float4 fa, fb;
+    const AT* __restrict__ xsrc; const AT* __restrict__ dsrc;
+    int lxy[NX], dxy[ND];
+    int Cs, cc, xq4, dq4; bool cok, dok;
 
+    __device__ __forceinline__ void init(const ConvBwdWArgs& A, int ci0, int co0) {
+        const int tid = threadIdx.x, c = ci0 + 4 * (tid % QX);
+        const bool two = (A.flags & F_TWO) && c >= A.C0;
+        Cs = two ? A.C1 : A.C0; cc = two ? c - A.C0 : c; cok = c < A.Cin; xq4 = 4 * (tid % QX);
+        xsrc = (two ? reinterpret_cast<const AT*>(A.x1) : reinterpret_cast<const AT*>(A.x0)) + cc;
+        fa = make_float4(1.f, 1.f, 1.f, 1.f); fb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((A.flags & F_AFF) && cok) { const float* ab = two ? A.ab1 : A.ab0; fa = ld4(ab + cc); fb = ld4(ab + Cs + cc); }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) { const int p = tid / QX + k * PPX; lxy[k] = p < NPX ? ((p / IW) << 8) | (p % IW) : -1; }
+        const int dc = co0 + 4 * (tid % QD);
+        dok = dc < A.Cout; dq4 = 4 * (tid % QD);
+        dsrc = reinterpret_cast<const AT*>(A.dz) + dc;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) { const int p = tid / QD + k * PPD; dxy[k] = p < NPD ? ((p / 32) << 8) | (p % 32) : -1; }
+    }
+    static __device__ __forceinline__ void origin(int y0, int x0, int& iy0, int& ix0) {
+        iy0 = UP ? y0 / 2 : y0 - (KH - 1) / 2; ix0 = UP ? x0 / 2 : x0 - (KH - 1) / 2;
+    }
     // issue the global loads of tile (b, y0, x0); out-of-range elements load nothing and become zeros
-    __device__ __forceinline__ void load(const ConvBwdWArgs& A, int b, int y0, int x0, int ci0, int co0) {
+    __device__ __forceinline__ void load(const ConvBwdWArgs& A, int b, int y0, int x0, int /*ci0*/, int /*co0*/) {
         const int Hs = UP ? A.H >> 1 : A.H, Ws = UP ? A.W >> 1 : A.W;
-        const int iy0 = UP ? y0 / 2 : y0 - (KH - 1) / 2, ix0 = UP ? x0 / 2 : x0 - (KH - 1) / 2;
+        int iy0, ix0; origin(y0, x0, iy0, ix0);
+        const AT* __restrict__ tb = xsrc + (((long long)b * Hs + iy0) * Ws + ix0) * Cs;     // wave-uniform (may point into the halo)
+        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= Hs && ix0 + IW <= Ws;
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
-            const int e = threadIdx.x + k * kBlock;
-            const int q = e % (CIC / 4), p = e / (CIC / 4), lx = p % IW, ly = p / IW;
-            const int gy = iy0 + ly, gx = ix0 + lx, c = ci0 + 4 * q;
-            xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < IH * IW * (CIC / 4) && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws && c < A.Cin)
-                xr[k] = lda4<AT>(x4_ptr<AT>(A, ((size_t)b * Hs + gy) * Ws + gx, c));
+            const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
+            bool ok = cok && lxy[k] >= 0;
+            if (!interior) ok = ok && (unsigned)(iy0 + ly) < (unsigned)Hs && (unsigned)(ix0 + lx) < (unsigned)Ws;
+            xr[k] = ok ? lda4<AT>(tb + (ly * Ws + lx) * Cs) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        const AT* __restrict__ db = dsrc + (((long long)b * A.H + y0) * A.W + x0) * A.Cout;
+        const bool dint = y0 + TH <= A.H && x0 + 32 <= A.W;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            const int e = threadIdx.x + k * kBlock;
-            const int q = e % (COC / 4), p = e / (COC / 4), px = p % 32, py = p / 32;
-            const int oy = y0 + py, ox = x0 + px, c = co0 + 4 * q;
-            dr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < TH * 32 * (COC / 4) && oy < A.H && ox < A.W && c < A.Cout)
-                dr[k] = lda4<AT>(reinterpret_cast<const AT*>(A.dz) + (((size_t)b * A.H + oy) * A.W + ox) * A.Cout + c);
+            const int py = dxy[k] >> 8, px = dxy[k] & 255;
+            bool ok = dok && dxy[k] >= 0;
+            if (!dint) ok = ok && y0 + py < A.H && x0 + px < A.W;
+            dr[k] = ok ? lda4<AT>(db + (py * A.W + px) * A.Cout) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     // write the loaded tile to LDS, applying the input transform; accumulates dz column sums (bias gradient)
-    __device__ __forceinline__ void store(const ConvBwdWArgs& A, float* Xs, float* Ds, int b, int y0, int x0, int ci0,
+    __device__ __forceinline__ void store(const ConvBwdWArgs& A, float* Xs, float* Ds, int b, int y0, int x0, int /*ci0*/,
                                           float4& bsum) {
         const int Hs = UP ? A.H >> 1 : A.H, Ws = UP ? A.W >> 1 : A.W;
-        const int iy0 = UP ? y0 / 2 : y0 - (KH - 1) / 2, ix0 = UP ? x0 / 2 : x0 - (KH - 1) / 2;
+        int iy0, ix0; origin(y0, x0, iy0, ix0);
+        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= Hs && ix0 + IW <= Ws;
+        const int basepix = (b * Hs + iy0) * Ws + ix0;                              // dropout element index only
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
-            const int e = threadIdx.x + k * kBlock;
-            if (e < IH * IW * (CIC / 4)) {
-                const int q = e % (CIC / 4), p = e / (CIC / 4), lx = p % IW, ly = p / IW;
-                const int gy = iy0 + ly, gx = ix0 + lx, c = ci0 + 4 * q;
-                float4 v = xr[k];
-                if (gy >= 0 && gy < Hs && gx >= 0 && gx < Ws && c < A.Cin)
-                    v = x4_xform(A, v, ((size_t)b * Hs + gy) * Ws + gx, c);   // out-of-range stays exactly zero
-                st4(Xs + (ly * IW + lx) * XSTRIDE + 4 * q, v);
+            if (lxy[k] < 0) continue;
+            const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
+            float4 v = xr[k];
+            bool in = cok;
+            if (!interior) in = in && (unsigned)(iy0 + ly) < (unsigned)Hs && (unsigned)(ix0 + lx) < (unsigned)Ws;
+            if (A.flags & F_AFF) {       // out-of-range stays exactly zero (padding is applied after the activation)
+                v.x = in ? fmaxf(fmaf(fa.x, v.x, fb.x), 0.f) : 0.f; v.y = in ? fmaxf(fmaf(fa.y, v.y, fb.y), 0.f) : 0.f;
+                v.z = in ? fmaxf(fmaf(fa.z, v.z, fb.z), 0.f) : 0.f; v.w = in ? fmaxf(fmaf(fa.w, v.w, fb.w), 0.f) : 0.f;
             }
+            if ((A.flags & F_DROP) && in) {
+                const uint32_t el = (uint32_t)((basepix + ly * Ws + lx) * Cs + cc);
+                v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
+                v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
+            }
+            st4(Xs + (ly * IW + lx) * XSTRIDE + xq4, v);
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            const int e = threadIdx.x + k * kBlock;
-            if (e < TH * 32 * (COC / 4)) {
-                st4(Ds + (e / (COC / 4)) * COC + 4 * (e % (COC / 4)), dr[k]);
-                bsum.x += dr[k].x; bsum.y += dr[k].y; bsum.z += dr[k].z; bsum.w += dr[k].w;
-            }
+            if (dxy[k] < 0) continue;
+            const int py = dxy[k] >> 8, px = dxy[k] & 255;
+            st4(Ds + (py * 32 + px) * COC + dq4, dr[k]);
+            bsum.x += dr[k].x; bsum.y += dr[k].y; bsum.z += dr[k].z; bsum.w += dr[k].w;
         }
     }
 };
@@ -115,7 +125,7 @@ __device__ __forceinline__ void bias_reduce(const ConvBwdWArgs& A, float* scratc
 // grid (npb, ceil(Cin/CIC), ceil(Cout/16))
 // ---------------------------------------------------------------------------------------------------------------
 template <int KH, int CIC, bool UP, typename AT>
-__global__ __launch_bounds__(kBlock) void conv_dw16_k(const ConvBwdWArgs A) {
+__global__ __launch_bounds__(kBlock, 3) void conv_dw16_k(const ConvBwdWArgs A) {   // 3 waves/SIMD: <= 168 VGPRs
     constexpr int TH = 8, TW = 32, TAPS = KH * KH, MROWS = TAPS * CIC, MTILES = (MROWS + 15) / 16;
     constexpr int IH = UP ? TH / 2 + 1 : TH + KH - 1, IW = UP ? TW / 2 + 1 : TW + KH - 1;
     constexpr int XS = IH * IW * CIC, DS = TH * TW * 16, RED = 4 * MTILES * 256;
@@ -139,6 +149,7 @@ __global__ __launch_bounds__(kBlock) void conv_dw16_k(const ConvBwdWArgs A) {
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
     TileStager<CIC, 16, IH, IW, UP, KH, TH, AT> st;
+    st.init(A, ci0, co0);
     auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
         b = tl / A.tiles; const int tile = tl % A.tiles;
         x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;
@@ -249,6 +260,7 @@ __global__ __launch_bounds__(kBlock) void conv_dwpair8_k(const ConvBwdWArgs A) {
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
     TileStager<CIC, 8, IH, IW, false, KH, TH, AT, XST> st;
+    st.init(A, ci0, 0);
     auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
         b = tl / A.tiles; const int tile = tl % A.tiles;
         x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;
@@ -352,6 +364,7 @@ __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
     const float* const db = Ds + kk * COC + i;
 
     TileStager<CIC, COC, IH, IW, UP, KH, TH, AT> st;
+    st.init(A, ci0, co0);
     auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
         b = tl / A.tiles; const int tile = tl % A.tiles;
         x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;
