@@ -185,55 +185,69 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
     constexpr int NPI = ((KC / 4) * IH * IW + kBlock - 1) / kBlock;
     constexpr int NPW = (TAPS * KC * (MB / 4) + kBlock - 1) / kBlock;
     float4 pin[NPI], pw[NPW];
-    auto load_chunk = [&](int c0) {
+    // Tile geometry is the same for every chunk: per slot the image-relative pixel offset (-1 = outside the image or
+    // past the tile) and the LDS offset are computed ONCE; a thread always serves channel quad q = tid % (KC/4), so per
+    // chunk only its source tensor (concat aware), channel offset and BN affine pair change -- fetched once per chunk,
+    // not once per element.
+    constexpr int QC = KC / 4, PPI = kBlock / QC;
+    static_assert(kBlock % QC == 0, "channel quad must be thread-invariant");
+    const int q4 = 4 * (tid % QC);
+    int goff[NPI], loff[NPI];
 #pragma unroll
-        for (int k = 0; k < NPI; ++k) {
-            const int e = tid + k * kBlock;
-            const int q = e % (KC / 4), p = e / (KC / 4), lx = p % IW, ly = p / IW;
-            const int gy = iy0 + ly, gx = ix0 + lx, c = c0 + 4 * q;
-            pin[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < (KC / 4) * IH * IW && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
-                const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
-                pin[k] = lda4<AT>(((A.flags & F_TWO) && c >= A.C0) ? reinterpret_cast<const AT*>(A.x1) + pix * A.C1 + (c - A.C0)
-                                                                  : reinterpret_cast<const AT*>(A.x0) + pix * A.C0 + c);
-            }
-        }
+    for (int k = 0; k < NPI; ++k) {
+        const int p = tid / QC + k * PPI, lx = p % IW, ly = p / IW, gy = iy0 + ly, gx = ix0 + lx;
+        const bool in = p < IH * IW && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi;
+        goff[k] = in ? gy * A.Wi + gx : -1;
+        loff[k] = p < IH * IW ? ly * IW + lx : -1;
+    }
+    // weight tile: slot -> (tap, kc, m4) fixed; element offset relative to channel c0 computed once
+    int woff[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int e = tid + k * kBlock, m4 = e % (MB / 4), r = e / (MB / 4), kc = r % KC, tap = r / KC, m = m0 + 4 * m4;
+        woff[k] = (e < TAPS * KC * (MB / 4) && m < A.Mout) ? (tap * A.Cin + kc) * A.w_ld + A.m_off + m : -1;
+    }
+    const size_t img = (size_t)b * A.Hi * A.Wi;
+    auto load_chunk = [&](int c0) {
+        const int c = c0 + q4;
+        const bool two = (A.flags & F_TWO) && c >= A.C0;
+        const int C = two ? A.C1 : A.C0;
+        const AT* __restrict__ src = (two ? reinterpret_cast<const AT*>(A.x1) + (c - A.C0) : reinterpret_cast<const AT*>(A.x0) + c) + img * C;
+        const bool cok = c < A.Cin;
+#pragma unroll
+        for (int k = 0; k < NPI; ++k)
+            pin[k] = (cok && goff[k] >= 0) ? lda4<AT>(src + (size_t)goff[k] * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* __restrict__ wsrc = A.w + (size_t)c0 * A.w_ld;
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
-            const int e = tid + k * kBlock;
-            const int m4 = e % (MB / 4), r = e / (MB / 4), kc = r % KC, tap = r / KC;
-            const int c = c0 + kc, m = m0 + 4 * m4;
-            pw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < TAPS * KC * (MB / 4) && c < A.Cin && m < A.Mout)
-                pw[k] = ld4(A.w + ((size_t)tap * A.Cin + c) * A.w_ld + A.m_off + m);
+            // (tap, kc) row exists for this chunk iff c0 + kc < Cin; kc = (slot / (MB/4)) % KC is slot-invariant
+            const int kc = ((tid + k * kBlock) / (MB / 4)) % KC;
+            pw[k] = (woff[k] >= 0 && c0 + kc < A.Cin) ? ld4(wsrc + woff[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_chunk = [&](int c0) {
+        const int c = c0 + q4;
+        const bool two = (A.flags & F_TWO) && c >= A.C0;
+        const int C = two ? A.C1 : A.C0, cc = two ? c - A.C0 : c;
+        const bool cok = c < A.Cin;
+        float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((A.flags & F_AFF) && cok) { const float* ab = two ? A.ab1 : A.ab0; fa = ld4(ab + cc); fb = ld4(ab + C + cc); }
 #pragma unroll
         for (int k = 0; k < NPI; ++k) {
-            const int e = tid + k * kBlock;
-            if (e < (KC / 4) * IH * IW) {
-                const int q = e % (KC / 4), p = e / (KC / 4), lx = p % IW, ly = p / IW;
-                const int gy = iy0 + ly, gx = ix0 + lx, c = c0 + 4 * q;
-                float4 v = pin[k];
-                if (gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
-                    const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
-                    const float* ab = A.ab0; int C = A.C0, cc = c;
-                    if ((A.flags & F_TWO) && c >= A.C0) { ab = A.ab1; C = A.C1; cc = c - A.C0; }
-                    if (A.flags & F_AFF) {
-                        const float4 a = ld4(ab + cc), bb = ld4(ab + C + cc);
-                        v.x = fmaxf(fmaf(a.x, v.x, bb.x), 0.f); v.y = fmaxf(fmaf(a.y, v.y, bb.y), 0.f);
-                        v.z = fmaxf(fmaf(a.z, v.z, bb.z), 0.f); v.w = fmaxf(fmaf(a.w, v.w, bb.w), 0.f);
-                    }
-                    if (A.flags & F_DROP) {
-                        const uint32_t el = (uint32_t)(pix * C + cc);
-                        v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
-                        v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
-                    }
-                }
-                float* d = Is + (4 * q) * PLANE + ly * IW + lx;
-                d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
+            if (loff[k] < 0) continue;
+            float4 v = pin[k];
+            const bool in = cok && goff[k] >= 0;
+            if (A.flags & F_AFF) {       // zero padding is applied AFTER the activation: out-of-image stays 0
+                v.x = in ? fmaxf(fmaf(fa.x, v.x, fb.x), 0.f) : 0.f; v.y = in ? fmaxf(fmaf(fa.y, v.y, fb.y), 0.f) : 0.f;
+                v.z = in ? fmaxf(fmaf(fa.z, v.z, fb.z), 0.f) : 0.f; v.w = in ? fmaxf(fmaf(fa.w, v.w, fb.w), 0.f) : 0.f;
             }
+            if ((A.flags & F_DROP) && in) {
+                const uint32_t el = (uint32_t)((img + goff[k]) * C + cc);
+                v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
+                v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
+            }
+            float* d = Is + q4 * PLANE + loff[k];
+            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
         }
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
