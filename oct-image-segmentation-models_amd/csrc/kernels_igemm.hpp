@@ -344,6 +344,111 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
     }
 }
 
+// ---- XCD-aware persistent tile walk without divisions.  Workgroups are dealt round-robin to the 8 XCDs (each with its
+// own L2), so block i serves XCD i % 8: the tile sequence is cut into 8 contiguous bands, one per XCD, and the blocks of
+// an XCD stride through their band -- tiles that share halo rows / columns are then read through the SAME L2 and each
+// XCD streams one contiguous region of the tensors.  A block visits tiles tl0, tl0 + step, ... < tlend; the origin
+// (b, ty, tx) is advanced by the decomposed stride with two carries. ----
+struct TileOrg { int b, ty, tx; };
+template <int TH, int TW>
+struct TileWalk {
+    int tiles_x, tiles_y, sb, sy, sx, tl0, tlend, step;
+    __device__ __forceinline__ void init(int tiles, int tx_, int total_tiles) {
+        constexpr int NX = 8;
+        if (gridDim.x % NX == 0) {
+            const int xcd = blockIdx.x % NX, chunk = (total_tiles + NX - 1) / NX;
+            step = gridDim.x / NX; tl0 = xcd * chunk + blockIdx.x / NX;
+            tlend = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
+        } else { step = gridDim.x; tl0 = blockIdx.x; tlend = total_tiles; }
+        tiles_x = tx_; tiles_y = tiles / tx_;
+        sb = step / tiles; sy = (step % tiles) / tiles_x; sx = step % tiles_x;
+    }
+    __device__ __forceinline__ TileOrg first(int tiles) const {
+        TileOrg o; const int r = tl0 % tiles; o.b = tl0 / tiles; o.ty = r / tiles_x; o.tx = r % tiles_x; return o;
+    }
+    __device__ __forceinline__ TileOrg next(TileOrg o) const {
+        o.tx += sx; int carry = 0;
+        if (o.tx >= tiles_x) { o.tx -= tiles_x; carry = 1; }
+        o.ty += sy + carry; carry = 0;
+        if (o.ty >= tiles_y) { o.ty -= tiles_y; carry = 1; }
+        o.b += sb + carry;
+        return o;
+    }
+};
+
+// ---- input-tile staging for the 8-output-channel kernels: global -> registers (prefetch) -> PLANAR LDS [c][row][col]
+// with the consumer-side transform (BN affine + ReLU, dropout, concat of two sources, zero padding).
+// Set up ONCE per thread: a thread always serves the same channel quad, so its source tensor, BN affine and LDS plane
+// are tile-invariant; per slot k only the packed local pixel (ly, lx) is kept. ----
+template <int CMAX, int IH, int IW, int IWP, int PLANE, int AMODE, int TH, int TW, typename AT, int NT = kBlock>
+struct ThinStager {
+    static constexpr int Q = CMAX / 4, PPI = NT / Q, NPIX = IH * IW, NPF = (NPIX + PPI - 1) / PPI;
+    const AT* __restrict__ src; float* lds_q;
+    int Csrc, cc; bool cok;
+    float4 fa, fb;
+    struct Buf { float4 v[NPF]; };     // one tile's worth of prefetched registers
+    int lxy[NPF];
+
+    __device__ __forceinline__ void init(const IgemmArgs& A, float* Is) {
+        const int tid = threadIdx.x, q = tid % Q, c = 4 * q;
+        const bool two = (A.flags & F_TWO) && c >= A.C0;
+        Csrc = two ? A.C1 : A.C0; cc = two ? c - A.C0 : c;
+        src = (two ? reinterpret_cast<const AT*>(A.x1) : reinterpret_cast<const AT*>(A.x0)) + cc;
+        cok = c < A.Cin;
+        fa = make_float4(1.f, 1.f, 1.f, 1.f); fb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((A.flags & F_AFF) && cok) { const float* ab = two ? A.ab1 : A.ab0; fa = ld4(ab + cc); fb = ld4(ab + Csrc + cc); }
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int p = tid / Q + k * PPI;
+            lxy[k] = p < NPIX ? ((p / IW) << 8) | (p % IW) : -1;
+        }
+        lds_q = Is + c * PLANE;
+    }
+    static __device__ __forceinline__ void origin(const TileOrg& o, int& iy0, int& ix0) {
+        const int y0 = o.ty * TH, x0 = o.tx * TW;
+        iy0 = AMODE == A_NORMAL ? y0 - 1 : y0 / 2; ix0 = AMODE == A_NORMAL ? x0 - 1 : x0 / 2;
+    }
+    // issue the global loads of tile o (out-of-image / absent channels load nothing and become zeros)
+    __device__ __forceinline__ void load(const IgemmArgs& A, const TileOrg& o, Buf& pf) {
+        int iy0, ix0; origin(o, iy0, ix0);
+        const long long basepix = ((long long)o.b * A.Hi + iy0) * A.Wi + ix0;       // wave-uniform (may point into the halo)
+        const AT* __restrict__ tb = src + basepix * Csrc;
+        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= A.Hi && ix0 + IW <= A.Wi;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
+            bool ok = cok && lxy[k] >= 0;
+            if (!interior) ok = ok && (unsigned)(iy0 + ly) < (unsigned)A.Hi && (unsigned)(ix0 + lx) < (unsigned)A.Wi;
+            pf.v[k] = ok ? lda4<AT>(tb + (ly * A.Wi + lx) * Csrc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // write the prefetched tile to LDS with the transform applied
+    __device__ __forceinline__ void store(const IgemmArgs& A, const TileOrg& o, const Buf& pf, int lds_off = 0) {
+        int iy0, ix0; origin(o, iy0, ix0);
+        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= A.Hi && ix0 + IW <= A.Wi;
+        const int basepix = (o.b * A.Hi + iy0) * A.Wi + ix0;                      // only used for the dropout element index
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            if (lxy[k] < 0) continue;
+            const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
+            float4 v = pf.v[k];
+            bool in = cok;
+            if (!interior) in = in && (unsigned)(iy0 + ly) < (unsigned)A.Hi && (unsigned)(ix0 + lx) < (unsigned)A.Wi;
+            if (A.flags & F_AFF) {       // zero padding is applied AFTER the activation: out-of-image stays 0
+                v.x = in ? fmaxf(fmaf(fa.x, v.x, fb.x), 0.f) : 0.f; v.y = in ? fmaxf(fmaf(fa.y, v.y, fb.y), 0.f) : 0.f;
+                v.z = in ? fmaxf(fmaf(fa.z, v.z, fb.z), 0.f) : 0.f; v.w = in ? fmaxf(fmaf(fa.w, v.w, fb.w), 0.f) : 0.f;
+            }
+            if (A.flags & F_DROP) {
+                const uint32_t el = (uint32_t)((basepix + ly * A.Wi + lx) * Csrc + cc);
+                if (in) { v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
+                          v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3); }
+            }
+            float* d = lds_q + lds_off + ly * IWP + lx;
+            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------------------
 // Persistent, software-pipelined variant for single-chunk layers (Cin <= KCP <= 16: the thin full-resolution layers,
 // which are HBM/latency-bound rather than MFMA-bound).  One block walks a strided list of pixel tiles:
@@ -391,62 +496,13 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
             bias[mt][q] = (EPI == EPI_FWD && m < A.Mout) ? ld4(A.bias + A.m_off + m) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 
-    auto origin = [&](int tl, int& b, int& y0, int& x0) {
-        b = tl / A.tiles; const int tile = tl % A.tiles;
-        x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;
-    };
-    auto in_origin = [&](int y0, int x0, int& iy0, int& ix0) {
-        iy0 = AMODE == A_NORMAL ? y0 - (KH - 1) / 2 : (AMODE == A_UPF ? y0 / 2 : 2 * y0 - 1);
-        ix0 = AMODE == A_NORMAL ? x0 - (KH - 1) / 2 : (AMODE == A_UPF ? x0 / 2 : 2 * x0 - 1);
-    };
-    float4 pf[NPF];
-    auto load_tile = [&](int tl) {
-        int b, y0, x0, iy0, ix0;
-        origin(tl, b, y0, x0); in_origin(y0, x0, iy0, ix0);
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const int e = tid + k * kBlock;
-            const int q = e % (KCP / 4), p = e / (KCP / 4), lx = p % IW, ly = p / IW;
-            const int gy = iy0 + ly, gx = ix0 + lx, c = 4 * q;
-            pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < (KCP / 4) * IH * IW && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
-                const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
-                const AT* src = ((A.flags & F_TWO) && c >= A.C0) ? reinterpret_cast<const AT*>(A.x1) + pix * A.C1 + (c - A.C0)
-                                                                  : reinterpret_cast<const AT*>(A.x0) + pix * A.C0 + c;
-                pf[k] = lda4<AT>(src);
-            }
-        }
-    };
-    auto store_tile = [&](int tl, float* dst) {
-        int b, y0, x0, iy0, ix0;
-        origin(tl, b, y0, x0); in_origin(y0, x0, iy0, ix0);
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const int e = tid + k * kBlock;
-            if (e < (KCP / 4) * IH * IW) {
-                const int q = e % (KCP / 4), p = e / (KCP / 4), lx = p % IW, ly = p / IW;
-                const int gy = iy0 + ly, gx = ix0 + lx, c = 4 * q;
-                float4 v = pf[k];
-                if (gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi && c < A.Cin) {
-                    const size_t pix = ((size_t)b * A.Hi + gy) * A.Wi + gx;
-                    const float* ab = A.ab0; int C = A.C0, cc = c;
-                    if ((A.flags & F_TWO) && c >= A.C0) { ab = A.ab1; C = A.C1; cc = c - A.C0; }
-                    if (A.flags & F_AFF) {
-                        const float4 a = ld4(ab + cc), bb = ld4(ab + C + cc);
-                        v.x = fmaxf(fmaf(a.x, v.x, bb.x), 0.f); v.y = fmaxf(fmaf(a.y, v.y, bb.y), 0.f);
-                        v.z = fmaxf(fmaf(a.z, v.z, bb.z), 0.f); v.w = fmaxf(fmaf(a.w, v.w, bb.w), 0.f);
-                    }
-                    if (A.flags & F_DROP) {
-                        const uint32_t el = (uint32_t)(pix * C + cc);
-                        v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
-                        v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3);
-                    }
-                }
-                float* d = dst + (4 * q) * PLANE + ly * IW + lx;
-                d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
-            }
-        }
-    };
+    // staging and tile walk shared with the 8-output-channel kernels: per-thread invariants set up once, interior
+    // tiles skip bounds tests, XCD-aware division-free walk (ThinStager / TileWalk above)
+    ThinStager<KCP, IH, IW, IW, PLANE, AMODE, TH, TW, AT> st;
+    st.init(A, Is[0]);
+    TileWalk<TH, TW> walk;
+    walk.init(A.tiles, A.tiles_x, A.total_tiles);
+    typename decltype(st)::Buf pf;
 
     int boff[NTW];
 #pragma unroll
@@ -460,16 +516,17 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
 #pragma unroll
         for (int r = 0; r < ACC; ++r) { s1[mt][r] = 0.f; s2[mt][r] = 0.f; }
 
-    const int step = gridDim.x;
-    if ((int)blockIdx.x < A.total_tiles) load_tile(blockIdx.x);
+    TileOrg cur = walk.first(A.tiles);
+    if (walk.tl0 < walk.tlend) st.load(A, cur, pf);
     int buf = 0;
-    for (int tl = blockIdx.x; tl < A.total_tiles; tl += step, buf ^= 1) {
+    for (int tl = walk.tl0; tl < walk.tlend; tl += walk.step, buf ^= 1) {
         const float* Ib = Is[buf];
-        store_tile(tl, Is[buf]);
+        st.store(A, cur, pf, buf * (KCP * PLANE));
         __syncthreads();            // tile image (and, first time, the weights) visible; buffer buf^1 is free again
-        if (tl + step < A.total_tiles) load_tile(tl + step);
-        int b, y0, x0;
-        origin(tl, b, y0, x0);
+        const TileOrg nxt = walk.next(cur);
+        if (tl + walk.step < walk.tlend) st.load(A, nxt, pf);
+        const int b = cur.b, y0 = cur.ty * TH, x0 = cur.tx * TW;
+        cur = nxt;
 
         // producer's z for the epilogue mask: issued now, consumed after the MFMA loop
         float4 zq[NTW][MTW][QUADS];

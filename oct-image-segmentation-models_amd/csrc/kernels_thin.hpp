@@ -14,110 +14,7 @@
 
 namespace oct {
 
-// ---- XCD-aware persistent tile walk without divisions.  Workgroups are dealt round-robin to the 8 XCDs (each with its
-// own L2), so block i serves XCD i % 8: the tile sequence is cut into 8 contiguous bands, one per XCD, and the blocks of
-// an XCD stride through their band -- tiles that share halo rows / columns are then read through the SAME L2 and each
-// XCD streams one contiguous region of the tensors.  A block visits tiles tl0, tl0 + step, ... < tlend; the origin
-// (b, ty, tx) is advanced by the decomposed stride with two carries. ----
-struct TileOrg { int b, ty, tx; };
-template <int TH, int TW>
-struct TileWalk {
-    int tiles_x, tiles_y, sb, sy, sx, tl0, tlend, step;
-    __device__ __forceinline__ void init(int tiles, int tx_, int total_tiles) {
-        constexpr int NX = 8;
-        if (gridDim.x % NX == 0) {
-            const int xcd = blockIdx.x % NX, chunk = (total_tiles + NX - 1) / NX;
-            step = gridDim.x / NX; tl0 = xcd * chunk + blockIdx.x / NX;
-            tlend = (xcd + 1) * chunk < total_tiles ? (xcd + 1) * chunk : total_tiles;
-        } else { step = gridDim.x; tl0 = blockIdx.x; tlend = total_tiles; }
-        tiles_x = tx_; tiles_y = tiles / tx_;
-        sb = step / tiles; sy = (step % tiles) / tiles_x; sx = step % tiles_x;
-    }
-    __device__ __forceinline__ TileOrg first(int tiles) const {
-        TileOrg o; const int r = tl0 % tiles; o.b = tl0 / tiles; o.ty = r / tiles_x; o.tx = r % tiles_x; return o;
-    }
-    __device__ __forceinline__ TileOrg next(TileOrg o) const {
-        o.tx += sx; int carry = 0;
-        if (o.tx >= tiles_x) { o.tx -= tiles_x; carry = 1; }
-        o.ty += sy + carry; carry = 0;
-        if (o.ty >= tiles_y) { o.ty -= tiles_y; carry = 1; }
-        o.b += sb + carry;
-        return o;
-    }
-};
-
-// ---- input-tile staging for the 8-output-channel kernels: global -> registers (prefetch) -> PLANAR LDS [c][row][col]
-// with the consumer-side transform (BN affine + ReLU, dropout, concat of two sources, zero padding).
-// Set up ONCE per thread: a thread always serves the same channel quad, so its source tensor, BN affine and LDS plane
-// are tile-invariant; per slot k only the packed local pixel (ly, lx) is kept. ----
-template <int CMAX, int IH, int IW, int IWP, int PLANE, int AMODE, int TH, int TW, typename AT, int NT = kBlock>
-struct ThinStager {
-    static constexpr int Q = CMAX / 4, PPI = NT / Q, NPIX = IH * IW, NPF = (NPIX + PPI - 1) / PPI;
-    const AT* __restrict__ src; float* lds_q;
-    int Csrc, cc; bool cok;
-    float4 fa, fb;
-    struct Buf { float4 v[NPF]; };     // one tile's worth of prefetched registers
-    int lxy[NPF];
-
-    __device__ __forceinline__ void init(const IgemmArgs& A, float* Is) {
-        const int tid = threadIdx.x, q = tid % Q, c = 4 * q;
-        const bool two = (A.flags & F_TWO) && c >= A.C0;
-        Csrc = two ? A.C1 : A.C0; cc = two ? c - A.C0 : c;
-        src = (two ? reinterpret_cast<const AT*>(A.x1) : reinterpret_cast<const AT*>(A.x0)) + cc;
-        cok = c < A.Cin;
-        fa = make_float4(1.f, 1.f, 1.f, 1.f); fb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((A.flags & F_AFF) && cok) { const float* ab = two ? A.ab1 : A.ab0; fa = ld4(ab + cc); fb = ld4(ab + Csrc + cc); }
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const int p = tid / Q + k * PPI;
-            lxy[k] = p < NPIX ? ((p / IW) << 8) | (p % IW) : -1;
-        }
-        lds_q = Is + c * PLANE;
-    }
-    static __device__ __forceinline__ void origin(const TileOrg& o, int& iy0, int& ix0) {
-        const int y0 = o.ty * TH, x0 = o.tx * TW;
-        iy0 = AMODE == A_NORMAL ? y0 - 1 : y0 / 2; ix0 = AMODE == A_NORMAL ? x0 - 1 : x0 / 2;
-    }
-    // issue the global loads of tile o (out-of-image / absent channels load nothing and become zeros)
-    __device__ __forceinline__ void load(const IgemmArgs& A, const TileOrg& o, Buf& pf) {
-        int iy0, ix0; origin(o, iy0, ix0);
-        const long long basepix = ((long long)o.b * A.Hi + iy0) * A.Wi + ix0;       // wave-uniform (may point into the halo)
-        const AT* __restrict__ tb = src + basepix * Csrc;
-        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= A.Hi && ix0 + IW <= A.Wi;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
-            bool ok = cok && lxy[k] >= 0;
-            if (!interior) ok = ok && (unsigned)(iy0 + ly) < (unsigned)A.Hi && (unsigned)(ix0 + lx) < (unsigned)A.Wi;
-            pf.v[k] = ok ? lda4<AT>(tb + (ly * A.Wi + lx) * Csrc) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    // write the prefetched tile to LDS with the transform applied
-    __device__ __forceinline__ void store(const IgemmArgs& A, const TileOrg& o, const Buf& pf) {
-        int iy0, ix0; origin(o, iy0, ix0);
-        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= A.Hi && ix0 + IW <= A.Wi;
-        const int basepix = (o.b * A.Hi + iy0) * A.Wi + ix0;                      // only used for the dropout element index
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            if (lxy[k] < 0) continue;
-            const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
-            float4 v = pf.v[k];
-            bool in = cok;
-            if (!interior) in = in && (unsigned)(iy0 + ly) < (unsigned)A.Hi && (unsigned)(ix0 + lx) < (unsigned)A.Wi;
-            if (A.flags & F_AFF) {       // zero padding is applied AFTER the activation: out-of-image stays 0
-                v.x = in ? fmaxf(fmaf(fa.x, v.x, fb.x), 0.f) : 0.f; v.y = in ? fmaxf(fmaf(fa.y, v.y, fb.y), 0.f) : 0.f;
-                v.z = in ? fmaxf(fmaf(fa.z, v.z, fb.z), 0.f) : 0.f; v.w = in ? fmaxf(fmaf(fa.w, v.w, fb.w), 0.f) : 0.f;
-            }
-            if (A.flags & F_DROP) {
-                const uint32_t el = (uint32_t)((basepix + ly * A.Wi + lx) * Csrc + cc);
-                if (in) { v.x *= drop_mul(A.drop, el); v.y *= drop_mul(A.drop, el + 1);
-                          v.z *= drop_mul(A.drop, el + 2); v.w *= drop_mul(A.drop, el + 3); }
-            }
-            float* d = lds_q + ly * IWP + lx;
-            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
-        }
-    }
-};
+// (TileWalk / ThinStager: kernels_igemm.hpp -- shared with the persistent MFMA kernel)
 
 // grid (nblk, 1, 1); requires Mout == 8, Cin <= 16 (Cin % 4 == 0), AMODE in {A_NORMAL (KH=3), A_UPF (KH=2)}
 template <int KH, int AMODE, int EPI, int CMAX, typename AT>
