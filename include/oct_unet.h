@@ -151,6 +151,10 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   thin-layer kernel instead of the (half-padded) 16x16 MFMA kernel.
  *   "pair8_min_tiles" (default 2048): number of pixel tiles from which 3x3 convs with 8 output channels run on the
  *   pixel-pair MFMA kernel (takes precedence over the VALU kernel).
+ *   "dw32_blocks" (512) / "dw16_blocks" (768): target block count of a backward-weights launch (wide / thin kernels; one
+ *   partial slab per block -- read when the handle is created, later launches never exceed the slabs allocated then).
+ *   "igemm_persistent_blocks" (1280): grid of the persistent igemm kernel.  "igemm_min_blocks" (512): a layer takes the
+ *   taller pixel tile only if that still yields this many blocks.
  *   "dwpair8_enable" (default 1): backward-weights of 3x3 layers with 8 output channels on the pixel-pair kernel
  *   (0 = the padded 16-column kernel).
  *   "pair8_geometry" (NWY*100 + NWX*10 + RPW in {221, 111}, default 221): waves per block (rows x columns)

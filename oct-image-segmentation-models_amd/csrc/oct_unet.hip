@@ -23,6 +23,9 @@ namespace {
 
 thread_local std::string g_err;
 int g_thin_min_tiles = 2048;      // pixel tiles from which 8-channel layers use the VALU thin kernel
+int g_dw32_blocks = 512, g_dw16_blocks = 768;   // target resident blocks of a backward-weights launch (wide / thin kernels)
+int g_igemm_p_blocks = 1280;      // persistent igemm grid
+int g_igemm_min_blocks = 512;     // a layer takes the taller pixel tile only if that still yields this many blocks
 int g_dwpair8 = 1;                // 3x3 layers with 8 output channels: pixel-pair backward-weights kernel (0 = padded 16-column kernel)
 int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
@@ -74,6 +77,7 @@ struct Layer {
     void* z = nullptr; void* g = nullptr;   // activation storage type (f32 or bf16)
     float* bn = nullptr;
     float* dwp = nullptr;  // this layer's dW slabs [npb][kh*kw*cin*cout + cout]
+    int dw_rows = 0;       // slabs allocated at creation: a launch never uses more (tuning options may change later)
     float* wt = nullptr;   // backward-data weights: transposed+flipped 3x3, or effective 3x3 of an up-conv (9*cin*cout)
 };
 
@@ -176,7 +180,7 @@ DwPlan dw_plan(const Layer& l, int B) {
     const int total = B * p.tiles;
     // one full round of resident blocks (no half-empty tail round): the wide kernel fits 2 blocks per CU (registers),
     // for the thin one 768 blocks measured best
-    const int target = p.kind == 32 ? 512 : 768;
+    const int target = p.kind == 32 ? g_dw32_blocks : g_dw16_blocks;
     p.npb = std::max(1, std::min(total, cdiv(target, p.chunks)));
     return p;
 }
@@ -221,7 +225,7 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
             const size_t wsz = (size_t)l.kh * l.kw * l.cin * l.cout + l.cout;
             const size_t rows = l.src == SRC_HEAD ? (size_t)(2048 + c.max_batch) : (size_t)dw_plan(l, c.max_batch).npb;
             float* dwp = (float*)take(rows * wsz * 4);
-            if (base) l.dwp = dwp;
+            if (base) { l.dwp = dwp; l.dw_rows = (int)rows; }
             dw_max = 0;
         }
     }
@@ -306,7 +310,7 @@ int launch_igemm_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, doubl
 template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN, int KCP>
 int launch_igemm_p(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
     a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH); a.total_tiles = B * a.tiles;
-    const int nblk = std::min(a.total_tiles, 1280);    // ~5 resident blocks per CU
+    const int nblk = std::min(a.total_tiles, g_igemm_p_blocks);    // ~5 resident blocks per CU
     dim3 grid(nblk, cdiv(a.Mout, MB), 1), block(kBlock);
     char nm[64]; snprintf(nm, sizeof nm, "conv_igemm_p_k<%d,%d,%d,%d,%d,%d,%d,%d,%s>", SHAPE, KH, AMODE, EPI, TH, MB, WN, KCP, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, layer, flops, bytes);
@@ -383,14 +387,14 @@ int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, do
         }
     }
     if (a.Mout <= 16) {
-        if (blocks(8, 16) >= 512) return launch_igemm_geo<16, KH, AMODE, EPI, 8, 16, 4>(a, B, s, layer, flops, bytes, rows);
+        if (blocks(8, 16) >= g_igemm_min_blocks) return launch_igemm_geo<16, KH, AMODE, EPI, 8, 16, 4>(a, B, s, layer, flops, bytes, rows);
         return launch_igemm_geo<16, KH, AMODE, EPI, 4, 16, 4>(a, B, s, layer, flops, bytes, rows);
     }
     if (a.Mout <= 32) {
-        if (blocks(8, 32) >= 512) return launch_igemm_geo<32, KH, AMODE, EPI, 8, 32, 4>(a, B, s, layer, flops, bytes, rows);
+        if (blocks(8, 32) >= g_igemm_min_blocks) return launch_igemm_geo<32, KH, AMODE, EPI, 8, 32, 4>(a, B, s, layer, flops, bytes, rows);
         return launch_igemm_geo<32, KH, AMODE, EPI, 4, 32, 4>(a, B, s, layer, flops, bytes, rows);
     }
-    if (blocks(4, 64) >= 512) return launch_igemm_geo<32, KH, AMODE, EPI, 4, 64, 4>(a, B, s, layer, flops, bytes, rows);
+    if (blocks(4, 64) >= g_igemm_min_blocks) return launch_igemm_geo<32, KH, AMODE, EPI, 4, 64, 4>(a, B, s, layer, flops, bytes, rows);
     return launch_igemm_geo<32, KH, AMODE, EPI, 2, 64, 2>(a, B, s, layer, flops, bytes, rows);
 }
 
@@ -590,7 +594,8 @@ int flush_reduce(oct_unet* h, hipStream_t s) {
 int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const void* dz, int B, hipStream_t s) {
     const Layer& l = h->plan.L[li];
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
-    const DwPlan p = dw_plan(l, B);
+    DwPlan p = dw_plan(l, B);
+    p.npb = std::min(p.npb, l.dw_rows);
     ConvBwdWArgs a{};
     a.x0 = sd.x0; a.ab0 = sd.ab0; a.C0 = sd.C0; a.x1 = sd.x1; a.ab1 = sd.ab1; a.C1 = sd.C1;
     a.flags = sd.flags | (l.drop_in ? F_DROP : 0);
@@ -1005,6 +1010,10 @@ int oct_boundary_maps(const unsigned char* labels, int B, int H, int W, int n_cl
 int oct_set_option(const char* name, int value) {
     if (!name) return fail(-1, "null option name");
     if (!strcmp(name, "igemm_persistent_min_tiles")) { g_persist_min_tiles = value < 1 ? 1 : value; return 0; }
+    if (!strcmp(name, "dw32_blocks")) { g_dw32_blocks = value < 64 ? 64 : value; return 0; }
+    if (!strcmp(name, "dw16_blocks")) { g_dw16_blocks = value < 64 ? 64 : value; return 0; }
+    if (!strcmp(name, "igemm_persistent_blocks")) { g_igemm_p_blocks = value < 8 ? 8 : value; return 0; }
+    if (!strcmp(name, "igemm_min_blocks")) { g_igemm_min_blocks = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "dwpair8_enable")) { g_dwpair8 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "pair8_geometry")) { if (value != 221 && value != 111) return fail(-1, "pair8_geometry must be 221 or 111"); g_pair_geo = value; return 0; }
     if (!strcmp(name, "pair8_min_tiles")) { g_pair_min_tiles = value < 1 ? 1 : value; return 0; }
