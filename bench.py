@@ -134,6 +134,14 @@ def main():
     torch.cuda.synchronize(); parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     scans_per_s = world * B * args.steps / dt
+    # which BASELINE.json configuration this run is: [1] = the headline (256x512x1, P=4, fp32, batch 32);
+    # [2] = 512x1024x1, P=5, bf16 storage, batch 64; anything else is labelled custom
+    if (H, W, C, args.pool_layers, args.act_dtype, B) == (256, 512, 3, 4, "f32", 32):
+        cfg_label = "configs[1]"
+    elif (H, W, args.pool_layers, args.act_dtype, B) == (512, 1024, 5, "bf16", 64):
+        cfg_label = "configs[2]"
+    else:
+        cfg_label = "custom (not a BASELINE configuration)"
     final_loss = float(loss4[0])
 
     # ---- inference: hipGraph-replayed forward (+argmax), batch 128, inputs resident ----
@@ -151,12 +159,12 @@ def main():
     infer_ms = parallel.max_over_ranks((time.perf_counter() - ti) / (n_inf * IB) * 1e3, dev)
 
     out = {
-        "metric": "B-scans/sec (train step), 256x512 3-class U-Net", "value": round(scans_per_s, 2),
+        "metric": f"B-scans/sec (train step), {H}x{W} {C}-class U-Net", "value": round(scans_per_s, 2),
         "unit": "B-scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.act_dtype == "f32" else "f32 math / bf16 activation storage",
         "data": "synthetic",
-        "config": {"workload": f"configs[1]: train step (fwd+Dice-macro+bwd+allreduce+Adam), per-GPU batch {B}, "
+        "config": {"workload": f"{cfg_label}: train step (fwd+Dice-macro+bwd+allreduce+Adam), per-GPU batch {B}, "
                                f"{H}x{W}x1, {C}-class, pool_layers={args.pool_layers}, start_neurons=8, random-init weights",
                    "global_batch": B * world, "parallelism": f"dp{world}"},
         "inference_ms_per_scan": round(infer_ms, 5), "inference_batch": IB, "final_loss": round(final_loss, 5),
