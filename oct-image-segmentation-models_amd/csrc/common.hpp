@@ -143,10 +143,13 @@ template <> __device__ inline float4 lda4<bf16_t>(const bf16_t* p) {
 }
 template <typename AT> __device__ inline void sta4(AT* p, const float4& v);
 template <> __device__ inline void sta4<float>(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+// gfx950 converts a pair per instruction (v_cvt_pk_bf16_f32, round to nearest even like f2bf above)
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
 template <> __device__ inline void sta4<bf16_t>(bf16_t* p, const float4& v) {
     uint2 u;
-    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    u.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_hw{v.x, v.y}, bf16x2_hw));
+    u.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_hw{v.z, v.w}, bf16x2_hw));
     *reinterpret_cast<uint2*>(p) = u;
 }
 template <typename AT> __device__ inline float lda1(const AT* p);
