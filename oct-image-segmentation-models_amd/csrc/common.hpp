@@ -141,6 +141,24 @@ template <> __device__ inline float4 lda4<bf16_t>(const bf16_t* p) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
                        __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
 }
+// Raw prefetch registers: what a 4-element activation load leaves in VGPRs BEFORE widening (float4 for f32 storage,
+// uint2 for bf16 storage).  Prefetched tiles are kept raw and widened when they are consumed: widening at the load
+// would put a use of the loaded data next to the load, which makes the compiler wait for every prefetch load in place
+// (measured: 3x SQ_WAIT_ANY in the bf16 dW kernels) -- and the raw form needs half the registers in bf16 mode.
+template <typename AT> struct Raw4;
+template <> struct Raw4<float> { using type = float4; };
+template <> struct Raw4<bf16_t> { using type = uint2; };
+template <typename AT> __device__ inline typename Raw4<AT>::type ldraw4(const AT* p);
+template <> __device__ inline float4 ldraw4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ inline uint2 ldraw4<bf16_t>(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+template <typename AT> __device__ inline typename Raw4<AT>::type raw_zero4();
+template <> __device__ inline float4 raw_zero4<float>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ inline uint2 raw_zero4<bf16_t>() { return make_uint2(0u, 0u); }
+__device__ inline float4 widen4(const float4& r) { return r; }
+__device__ inline float4 widen4(const uint2& u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
 template <typename AT> __device__ inline void sta4(AT* p, const float4& v);
 template <> __device__ inline void sta4<float>(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 // gfx950 converts a pair per instruction (v_cvt_pk_bf16_f32, round to nearest even like f2bf above)

@@ -22,7 +22,7 @@ template <int CIC, int COC, int IH, int IW, bool UP, int KH, int TH, typename AT
 struct TileStager {
     static constexpr int QX = CIC / 4, PPX = kBlock / QX, NPX = IH * IW, NX = (NPX + PPX - 1) / PPX;   // X tile
     static constexpr int QD = COC / 4, PPD = kBlock / QD, NPD = TH * 32, ND = (NPD + PPD - 1) / PPD;   // dz tile
-    float4 xr[NX], dr[ND];
+    typename Raw4<AT>::type xr[NX], dr[ND];     // raw prefetch registers (widened in store())
     float4 fa, fb;
     const AT* __restrict__ xsrc; const AT* __restrict__ dsrc;
     int lxy[NX], dxy[ND];
@@ -57,7 +57,7 @@ struct TileStager {
             const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
             bool ok = cok && lxy[k] >= 0;
             if (!interior) ok = ok && (unsigned)(iy0 + ly) < (unsigned)Hs && (unsigned)(ix0 + lx) < (unsigned)Ws;
-            xr[k] = ok ? lda4<AT>(tb + (ly * Ws + lx) * Cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xr[k] = ok ? ldraw4<AT>(tb + (ly * Ws + lx) * Cs) : raw_zero4<AT>();
         }
         const AT* __restrict__ db = dsrc + (((long long)b * A.H + y0) * A.W + x0) * A.Cout;
         const bool dint = y0 + TH <= A.H && x0 + 32 <= A.W;
@@ -66,7 +66,7 @@ struct TileStager {
             const int py = dxy[k] >> 8, px = dxy[k] & 255;
             bool ok = dok && dxy[k] >= 0;
             if (!dint) ok = ok && y0 + py < A.H && x0 + px < A.W;
-            dr[k] = ok ? lda4<AT>(db + (py * A.W + px) * A.Cout) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dr[k] = ok ? ldraw4<AT>(db + (py * A.W + px) * A.Cout) : raw_zero4<AT>();
         }
     }
     // write the loaded tile to LDS, applying the input transform; accumulates dz column sums (bias gradient)
@@ -80,7 +80,7 @@ struct TileStager {
         for (int k = 0; k < NX; ++k) {
             if (lxy[k] < 0) continue;
             const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
-            float4 v = xr[k];
+            float4 v = widen4(xr[k]);
             bool in = cok;
             if (!interior) in = in && (unsigned)(iy0 + ly) < (unsigned)Hs && (unsigned)(ix0 + lx) < (unsigned)Ws;
             if (A.flags & F_AFF) {       // out-of-range stays exactly zero (padding is applied after the activation)
@@ -98,8 +98,9 @@ struct TileStager {
         for (int k = 0; k < ND; ++k) {
             if (dxy[k] < 0) continue;
             const int py = dxy[k] >> 8, px = dxy[k] & 255;
-            st4(Ds + (py * 32 + px) * COC + dq4, dr[k]);
-            bsum.x += dr[k].x; bsum.y += dr[k].y; bsum.z += dr[k].z; bsum.w += dr[k].w;
+            const float4 d = widen4(dr[k]);
+            st4(Ds + (py * 32 + px) * COC + dq4, d);
+            bsum.x += d.x; bsum.y += d.y; bsum.z += d.z; bsum.w += d.w;
         }
     }
 };

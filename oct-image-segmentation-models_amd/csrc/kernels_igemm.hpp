@@ -184,7 +184,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
     // the MFMA sweep of chunk c and written to LDS after it
     constexpr int NPI = ((KC / 4) * IH * IW + kBlock - 1) / kBlock;
     constexpr int NPW = (TAPS * KC * (MB / 4) + kBlock - 1) / kBlock;
-    float4 pin[NPI], pw[NPW];
+    typename Raw4<AT>::type pin[NPI];            // raw prefetch registers (widened in store_chunk)
+    float4 pw[NPW];
     // Tile geometry is the same for every chunk: per slot the image-relative pixel offset (-1 = outside the image or
     // past the tile) and the LDS offset are computed ONCE; a thread always serves channel quad q = tid % (KC/4), so per
     // chunk only its source tensor (concat aware), channel offset and BN affine pair change -- fetched once per chunk,
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
         const bool cok = c < A.Cin;
 #pragma unroll
         for (int k = 0; k < NPI; ++k)
-            pin[k] = (cok && goff[k] >= 0) ? lda4<AT>(src + (size_t)goff[k] * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pin[k] = (cok && goff[k] >= 0) ? ldraw4<AT>(src + (size_t)goff[k] * C) : raw_zero4<AT>();
         const float* __restrict__ wsrc = A.w + (size_t)c0 * A.w_ld;
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
 #pragma unroll
         for (int k = 0; k < NPI; ++k) {
             if (loff[k] < 0) continue;
-            float4 v = pin[k];
+            float4 v = widen4(pin[k]);
             const bool in = cok && goff[k] >= 0;
             if (A.flags & F_AFF) {       // zero padding is applied AFTER the activation: out-of-image stays 0
                 v.x = in ? fmaxf(fmaf(fa.x, v.x, fb.x), 0.f) : 0.f; v.y = in ? fmaxf(fmaf(fa.y, v.y, fb.y), 0.f) : 0.f;
@@ -386,7 +387,7 @@ struct ThinStager {
     const AT* __restrict__ src; float* lds_q;
     int Csrc, cc; bool cok;
     float4 fa, fb;
-    struct Buf { float4 v[NPF]; };     // one tile's worth of prefetched registers
+    struct Buf { typename Raw4<AT>::type v[NPF]; };     // one tile's worth of RAW prefetched registers (widened in store())
     int lxy[NPF];
 
     __device__ __forceinline__ void init(const IgemmArgs& A, float* Is) {
@@ -419,7 +420,7 @@ struct ThinStager {
             const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
             bool ok = cok && lxy[k] >= 0;
             if (!interior) ok = ok && (unsigned)(iy0 + ly) < (unsigned)A.Hi && (unsigned)(ix0 + lx) < (unsigned)A.Wi;
-            pf.v[k] = ok ? lda4<AT>(tb + (ly * A.Wi + lx) * Csrc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pf.v[k] = ok ? ldraw4<AT>(tb + (ly * A.Wi + lx) * Csrc) : raw_zero4<AT>();
         }
     }
     // write the prefetched tile to LDS with the transform applied
@@ -431,7 +432,7 @@ struct ThinStager {
         for (int k = 0; k < NPF; ++k) {
             if (lxy[k] < 0) continue;
             const int ly = lxy[k] >> 8, lx = lxy[k] & 255;
-            float4 v = pf.v[k];
+            float4 v = widen4(pf.v[k]);
             bool in = cok;
             if (!interior) in = in && (unsigned)(iy0 + ly) < (unsigned)A.Hi && (unsigned)(ix0 + lx) < (unsigned)A.Wi;
             if (A.flags & F_AFF) {       // zero padding is applied AFTER the activation: out-of-image stays 0
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
         cur = nxt;
 
         // producer's z for the epilogue mask: issued now, consumed after the MFMA loop
-        float4 zq[NTW][MTW][QUADS];
+        typename Raw4<AT>::type zq[NTW][MTW][QUADS];     // raw: widened after the sweep
         if constexpr (EPI == EPI_MASK) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
 #pragma unroll
                     for (int q = 0; q < QUADS; ++q) {
                         const int m = m0 + (wm * MTW + mt) * MT + S::quad_base(q, h);
-                        zq[nt][mt][q] = (pvalid && m < A.Mout) ? lda4<AT>(reinterpret_cast<const AT*>(A.zin) + pix * A.Mout + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        zq[nt][mt][q] = (pvalid && m < A.Mout) ? ldraw4<AT>(reinterpret_cast<const AT*>(A.zin) + pix * A.Mout + m) : raw_zero4<AT>();
                     }
             }
         }
@@ -578,7 +579,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
                             s1[mt][4 * q + k] += u; s2[mt][4 * q + k] += u * u;
                         }
                     } else if constexpr (EPI == EPI_MASK) {
-                        const float zz[4] = {zq[nt][mt][q].x, zq[nt][mt][q].y, zq[nt][mt][q].z, zq[nt][mt][q].w};
+                        const float4 zw = widen4(zq[nt][mt][q]);
+                        const float zz[4] = {zw.x, zw.y, zw.z, zw.w};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int c = valid ? m + k : 0;

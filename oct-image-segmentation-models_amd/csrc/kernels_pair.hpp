@@ -78,13 +78,13 @@ __global__ __launch_bounds__(64 * NWY * NWX) void conv_pair8_k(const IgemmArgs A
       for (int rg = 0; rg < RPW; ++rg) {
         const int b = o.b, y0 = o.ty * TH + ry0 + 4 * rg, x = o.tx * TW + cx0 + 2 * n + pj;
         const float* const bb = bbase + 4 * rg * IWP;
-        float4 zq[4];
+        typename Raw4<AT>::type zq[4];       // raw: widened after the sweep
         if constexpr (EPI == EPI_MASK) {    // producer's z for the ReLU mask: in flight during the MFMA loop
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = y0 + r < A.Ho && x < A.Wo;
                 const AT* zp = reinterpret_cast<const AT*>(A.zin) + (((size_t)b * A.Ho + (ok ? y0 + r : 0)) * A.Wo + (ok ? x : 0)) * M + ch0;
-                zq[r] = ok ? lda4<AT>(zp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                zq[r] = ok ? ldraw4<AT>(zp) : raw_zero4<AT>();
             }
         }
 
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(64 * NWY * NWX) void conv_pair8_k(const IgemmArgs A
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { const float t = valid ? v[i] : 0.f; s1[i] += t; s2[i] += t * t; }
             } else if constexpr (EPI == EPI_MASK) {
-                const float zz[4] = {zq[r].x, zq[r].y, zq[r].z, zq[r].w};
+                const float4 zw = widen4(zq[r]);
+                const float zz[4] = {zw.x, zw.y, zw.z, zw.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float yv = fmaf(bna[i], zz[i], bnb[i]);

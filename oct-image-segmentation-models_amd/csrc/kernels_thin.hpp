@@ -54,14 +54,14 @@ __global__ __launch_bounds__(kBlock) void conv_thin8_k(const IgemmArgs A, const 
         cur = nxt;
         const int y = y0 + ty, x = x0 + 2 * tx;
         const bool rowok = y < A.Ho;
-        float4 zq[PX][2];
+        typename Raw4<AT>::type zq[PX][2];   // raw: widened after the FMA loop
         if constexpr (EPI == EPI_MASK) {    // producer's z for the ReLU mask: in flight during the FMA loop
 #pragma unroll
             for (int p = 0; p < PX; ++p) {
                 const bool ok = rowok && x + p < A.Wo;
                 const AT* zp = reinterpret_cast<const AT*>(A.zin) + (((size_t)b * A.Ho + (ok ? y : 0)) * A.Wo + (ok ? x + p : 0)) * M;
-                zq[p][0] = ok ? lda4<AT>(zp) : make_float4(0.f, 0.f, 0.f, 0.f);
-                zq[p][1] = ok ? lda4<AT>(zp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                zq[p][0] = ok ? ldraw4<AT>(zp) : raw_zero4<AT>();
+                zq[p][1] = ok ? ldraw4<AT>(zp + 4) : raw_zero4<AT>();
             }
         }
 
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(kBlock) void conv_thin8_k(const IgemmArgs A, const 
 #pragma unroll
                 for (int m = 0; m < M; ++m) { const float u = valid ? v[m] : 0.f; s1[m] += u; s2[m] += u * u; }
             } else if constexpr (EPI == EPI_MASK) {
-                const float zz[M] = {zq[p][0].x, zq[p][0].y, zq[p][0].z, zq[p][0].w, zq[p][1].x, zq[p][1].y, zq[p][1].z, zq[p][1].w};
+                const float4 z0 = widen4(zq[p][0]), z1 = widen4(zq[p][1]);
+                const float zz[M] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     const float yv = fmaf(A.bnin[BN_A * M + m], zz[m], A.bnin[BN_B * M + m]);
