@@ -130,7 +130,9 @@ __global__ __launch_bounds__(kBlock) void conv_first_fwd_k(const ConvFwdArgs A, 
     constexpr int TH = 8, TW = 128, XH = TH + 2, XW = TW + 2;
     __shared__ float Xs[XH * XW];
     __shared__ float red[256];
+    __shared__ float lut_s[256];          // the float32(i/255.0) table, copied once: lookups become LDS reads
     const int t = threadIdx.x, xl = t & 31, row = t >> 5;
+    lut_s[t] = c_u8_lut[t];
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -138,14 +140,22 @@ __global__ __launch_bounds__(kBlock) void conv_first_fwd_k(const ConvFwdArgs A, 
         const int b = tl / tiles, tile = tl % tiles;
         const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
         __syncthreads();
-        for (int i = t; i < XH * XW; i += kBlock) {
-            const int cy = i / XW, cx = i % XW, iy = y0 + cy - 1, ix = x0 + cx - 1;
-            float v = 0.f;
-            if (iy >= 0 && iy < A.H && ix >= 0 && ix < A.W) {
-                const size_t pix = ((size_t)b * A.H + iy) * A.W + ix;
-                v = x_is_u8 ? c_u8_lut[reinterpret_cast<const unsigned char*>(A.x0)[pix]] : reinterpret_cast<const float*>(A.x0)[pix];
+        {   // all image loads of the tile are issued before any is used (the /255 table lookup is a dependent access)
+            constexpr int NS = (XH * XW + kBlock - 1) / kBlock;
+            unsigned int rb[NS]; float rf[NS]; bool in[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = t + k * kBlock, cy = i / XW, cx = i % XW, iy = y0 + cy - 1, ix = x0 + cx - 1;
+                in[k] = i < XH * XW && iy >= 0 && iy < A.H && ix >= 0 && ix < A.W;
+                const size_t pix = in[k] ? ((size_t)b * A.H + iy) * A.W + ix : 0;
+                rb[k] = 0; rf[k] = 0.f;
+                if (in[k]) { if (x_is_u8) rb[k] = reinterpret_cast<const unsigned char*>(A.x0)[pix]; else rf[k] = reinterpret_cast<const float*>(A.x0)[pix]; }
             }
-            Xs[i] = v;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int i = t + k * kBlock;
+                if (i < XH * XW) Xs[i] = in[k] ? (x_is_u8 ? lut_s[rb[k]] : rf[k]) : 0.f;
+            }
         }
         __syncthreads();
         const int y = y0 + row;
