@@ -270,6 +270,38 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
     }
 
     // ---- epilogue ----
+    // Per-channel constants of this M block (bias, or the producer's BN record a / b / mean / rstd) are copied ONCE into
+    // the weight buffer, which is free now, and every z value the mask needs is requested up front into raw registers:
+    // inside the output loop a global load cannot be moved above the preceding (possibly aliasing) store, so loading
+    // there costs one memory round trip per quad.
+    __syncthreads();                       // every wave has finished its last sweep over Ws / Is
+    float* const epi = Ws;                 // [4][MB] (EPI_MASK: BN_A, BN_B, BN_MEAN, BN_RSTD rows) or [MB] (EPI_FWD: bias)
+    if constexpr (EPI == EPI_FWD) {
+        for (int e = tid; e < MB; e += kBlock) epi[e] = m0 + e < A.Mout ? A.bias[A.m_off + m0 + e] : 0.f;
+    } else if constexpr (EPI == EPI_MASK) {
+        for (int e = tid; e < 4 * MB; e += kBlock) {
+            const int arr = e / MB, m = m0 + e % MB;
+            epi[e] = m < A.Mout ? A.bnin[arr * A.Mout + m] : 0.f;
+        }
+    }
+    typename Raw4<AT>::type zraw[EPI == EPI_MASK ? NTW : 1][EPI == EPI_MASK ? MTW : 1][EPI == EPI_MASK ? QUADS : 1];
+    if constexpr (EPI == EPI_MASK) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int t = wn * NTW + nt, r = t / NPR, xs = (t % NPR) * NT + j;
+            const int y = y0 + r, x = x0 + xs;
+            const bool pvalid = y < A.Ho && x < A.Wo;
+            const size_t pix = pvalid ? ((size_t)b * A.Ho + y) * A.Wo + x : 0;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int q = 0; q < QUADS; ++q) {
+                    const int m = m0 + (wm * MTW + mt) * MT + S::quad_base(q, h);
+                    zraw[nt][mt][q] = (pvalid && m < A.Mout) ? ldraw4<AT>(reinterpret_cast<const AT*>(A.zin) + pix * A.Mout + m) : raw_zero4<AT>();
+                }
+        }
+    }
+    __syncthreads();                       // epi visible
     float s1[MTW][ACC], s2[MTW][ACC];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -286,12 +318,12 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
         for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
             for (int q = 0; q < QUADS; ++q) {
-                const int m = m0 + (wm * MTW + mt) * MT + S::quad_base(q, h);
+                const int ml = (wm * MTW + mt) * MT + S::quad_base(q, h), m = m0 + ml;     // channel within the block / overall
                 const bool valid = pvalid && m < A.Mout;
                 float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
                 if constexpr (EPI == EPI_FWD) {
                     if (valid) {
-                        const float4 bs = ld4(A.bias + A.m_off + m);
+                        const float4 bs = ld4(epi + ml);
                         v[0] += bs.x; v[1] += bs.y; v[2] += bs.z; v[3] += bs.w;
                     }
 #pragma unroll
@@ -300,16 +332,20 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_k(const IgemmArgs A) {
                         s1[mt][4 * q + k] += u; s2[mt][4 * q + k] += u * u;
                     }
                 } else if constexpr (EPI == EPI_MASK) {
-                    const float4 zq = valid ? lda4<AT>(reinterpret_cast<const AT*>(A.zin) + pix * A.Mout + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 zq = widen4(zraw[nt][mt][q]);
                     const float zz[4] = {zq.x, zq.y, zq.z, zq.w};
+                    const float4 ea = ld4(epi + BN_A * MB + ml), eb = ld4(epi + BN_B * MB + ml);
+                    const float4 em = ld4(epi + BN_MEAN * MB + ml), er = ld4(epi + BN_RSTD * MB + ml);
+                    const float ka[4] = {ea.x, ea.y, ea.z, ea.w}, kb[4] = {eb.x, eb.y, eb.z, eb.w};
+                    const float km[4] = {em.x, em.y, em.z, em.w}, kr[4] = {er.x, er.y, er.z, er.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int c = valid ? m + k : 0;
-                        const float yv = fmaf(A.bnin[BN_A * A.Mout + c], zz[k], A.bnin[BN_B * A.Mout + c]);
+                        const float yv = fmaf(ka[k], zz[k], kb[k]);
                         float gv = v[k];
                         if (A.drop_out) gv *= drop_mul(A.drop, (uint32_t)(pix * A.Mout + c));
                         gv = (valid && yv > 0.f) ? gv : 0.f;
-                        const float xh = (zz[k] - A.bnin[BN_MEAN * A.Mout + c]) * A.bnin[BN_RSTD * A.Mout + c];
+                        const float xh = (zz[k] - km[k]) * kr[k];
                         v[k] = gv; s1[mt][4 * q + k] += gv; s2[mt][4 * q + k] += gv * xh;
                     }
                 }
