@@ -511,6 +511,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
     __shared__ float Is[2][KCP * PLANE];
     __shared__ float Ws[TAPS * KCP * MB];
     __shared__ float red[RED];
+    __shared__ float epi[4 * MB];          // EPI_MASK: the producer's BN record rows a / b / mean / rstd of this M block
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wm = wave / WN;
@@ -523,6 +524,12 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (kc < A.Cin && m < A.Mout) v = ld4(A.w + ((size_t)tap * A.Cin + kc) * A.w_ld + A.m_off + m);
         st4(Ws + (tap * KCP + kc) * MB + 4 * m4, v);
+    }
+    if constexpr (EPI == EPI_MASK) {        // once per persistent block; read from LDS in every tile's epilogue (a global
+        for (int e = tid; e < 4 * MB; e += kBlock) {     // load there would sit behind the previous, possibly aliasing, store)
+            const int arr = e / MB, m = m0 + e % MB;
+            epi[e] = m < A.Mout ? A.bnin[arr * A.Mout + m] : 0.f;
+        }
     }
     float4 bias[MTW][QUADS];
 #pragma unroll
@@ -617,14 +624,19 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_p_k(const IgemmArgs A) {
                     } else if constexpr (EPI == EPI_MASK) {
                         const float4 zw = widen4(zq[nt][mt][q]);
                         const float zz[4] = {zw.x, zw.y, zw.z, zw.w};
+                        const int ml = m - m0;
+                        const float4 ea = ld4(epi + BN_A * MB + ml), eb = ld4(epi + BN_B * MB + ml);
+                        const float4 em = ld4(epi + BN_MEAN * MB + ml), er = ld4(epi + BN_RSTD * MB + ml);
+                        const float ka[4] = {ea.x, ea.y, ea.z, ea.w}, kb[4] = {eb.x, eb.y, eb.z, eb.w};
+                        const float km[4] = {em.x, em.y, em.z, em.w}, kr[4] = {er.x, er.y, er.z, er.w};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int c = valid ? m + k : 0;
-                            const float yv = fmaf(A.bnin[BN_A * A.Mout + c], zz[k], A.bnin[BN_B * A.Mout + c]);
+                            const float yv = fmaf(ka[k], zz[k], kb[k]);
                             float gv = v[k];
                             if (A.drop_out) gv *= drop_mul(A.drop, (uint32_t)(pix * A.Mout + c));
                             gv = (valid && yv > 0.f) ? gv : 0.f;
-                            const float xh = (zz[k] - A.bnin[BN_MEAN * A.Mout + c]) * A.bnin[BN_RSTD * A.Mout + c];
+                            const float xh = (zz[k] - km[k]) * kr[k];
                             v[k] = gv; s1[mt][4 * q + k] += gv; s2[mt][4 * q + k] += gv * xh;
                         }
                     }
