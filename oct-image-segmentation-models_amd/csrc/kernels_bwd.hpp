@@ -188,6 +188,32 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_k(AT* __restrict__ g, con
     }
 }
 
+// bf16 storage, channel count a multiple of 8: 8 elements per thread so that every access is 16 bytes per lane (the
+// 4-element form moves 8 bytes per lane and reaches 4.5 TB/s instead of 6).  Same arithmetic, same operation order.
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply8_bf16_k(bf16_t* __restrict__ g, const bf16_t* __restrict__ z,
+                                                              const float* __restrict__ bn, const float* __restrict__ gamma,
+                                                              size_t n8, int C) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (size_t)gridDim.x * kBlock) {
+        const int c = (int)((i * 8) % C);
+        const uint4 gr = *reinterpret_cast<const uint4*>(g + i * 8), zr = *reinterpret_cast<const uint4*>(z + i * 8);
+        const float4 gv[2] = {widen4(make_uint2(gr.x, gr.y)), widen4(make_uint2(gr.z, gr.w))};
+        const float4 zv[2] = {widen4(make_uint2(zr.x, zr.y)), widen4(make_uint2(zr.z, zr.w))};
+        bf16_t* out = g + i * 8;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int cc = c + 4 * hlf;
+            const float4 mean = ld4(bn + BN_MEAN * C + cc), rstd = ld4(bn + BN_RSTD * C + cc);
+            const float4 c1 = ld4(bn + BN_C1 * C + cc), c2 = ld4(bn + BN_C2 * C + cc), gm = ld4(gamma + cc);
+            float4 o;
+            o.x = gm.x * rstd.x * (gv[hlf].x - c1.x - (zv[hlf].x - mean.x) * rstd.x * c2.x);
+            o.y = gm.y * rstd.y * (gv[hlf].y - c1.y - (zv[hlf].y - mean.y) * rstd.y * c2.y);
+            o.z = gm.z * rstd.z * (gv[hlf].z - c1.z - (zv[hlf].z - mean.z) * rstd.z * c2.z);
+            o.w = gm.w * rstd.w * (gv[hlf].w - c1.w - (zv[hlf].w - mean.w) * rstd.w * c2.w);
+            sta4<bf16_t>(out + 4 * hlf, o);       // the two 8-byte halves of one 16-byte line: merged by the compiler / L2
+        }
+    }
+}
+
 // ---- head backward: Dice gradient -> softmax Jacobian -> 1x1 conv backward (data AND weights) -> mask + stats ------
 // Everything the head needs is in registers here (y, p, dlogits), so its dW/db are accumulated in the same pass:
 // no dlogits tensor, no second read of z.  grid (nblk, B); a block walks chunks of one image and emits one row of

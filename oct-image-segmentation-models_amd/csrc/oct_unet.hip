@@ -655,6 +655,14 @@ int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s) {
     const size_t n4 = (size_t)B * l.H * l.W * l.cout / 4;
     const int grid = (int)std::min<size_t>((n4 + kBlock - 1) / kBlock, 8192);
     const int bf = h->cfg.dtype;
+    if (bf && l.cout % 8 == 0) {           // 16-byte accesses in bf16 mode
+        const size_t n8 = n4 / 2;
+        const int grid8 = (int)std::min<size_t>((n8 + kBlock - 1) / kBlock, 8192);
+        ProfScope ps(s, "bn_bwd_apply8_bf16_k", l.name, 0, (double)n4 * 8 * 3);
+        bn_bwd_apply8_bf16_k<<<grid8, kBlock, 0, s>>>((bf16_t*)l.g, (const bf16_t*)l.z, l.bn, h->params + l.gamma_off, n8, l.cout);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
     ProfScope ps(s, bf ? "bn_bwd_apply_k<unsigned short>" : "bn_bwd_apply_k<float>", l.name, 0, (double)n4 * (bf ? 8 : 16) * 3);
     AT_DISPATCH(bf, bn_bwd_apply_k<AT><<<grid, kBlock, 0, s>>>((AT*)l.g, (const AT*)l.z, l.bn, h->params + l.gamma_off, n4, l.cout));
     HIP_OK(hipGetLastError());
