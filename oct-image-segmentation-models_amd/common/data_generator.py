@@ -128,6 +128,9 @@ class BatchGenerator:
         return self._sparse_cache
 
     def next_batch_u8(self):
+        if self.images_u8.dtype != np.uint8:
+            raise TypeError(f"next_batch_u8 needs a uint8 image array, the dataset holds {self.images_u8.dtype}; "
+                            "use get_batch_list() (float32(images) / 255)")
         idx = self._next_indices()
         return self.images_u8[idx], self.sparse_labels()[idx]
 
@@ -145,7 +148,10 @@ class DataGenerator:
     def __init__(self, images: np.ndarray, labels: np.ndarray, batch_size: int, aug_fn_args: List[Tuple],
                  aug_mode: str, aug_probs: Tuple, aug_fly: bool, preprocess_input_fn: Callable,
                  seed: Optional[int] = None):
-        self.oct_fast_path = aug_mode == "none"   # uint8 fast path only without augmentation
+        # uint8 fast path (the /255 happens on the GPU) only without augmentation AND only for uint8 storage: the
+        # reference divides by 255 whatever the dataset's dtype (data_generator.py:76), so any other dtype goes through
+        # get_batch_list(), which computes float32(images) / 255 on the host
+        self.oct_fast_path = aug_mode == "none" and np.asarray(images).dtype == np.uint8
         self.batch_gen = BatchGenerator(images=images, labels=labels, batch_size=batch_size, aug_fn_args=aug_fn_args,
                                         aug_mode=aug_mode, aug_probs=aug_probs, aug_fly=aug_fly,
                                         preprocess_input_fn=preprocess_input_fn, seed=seed)

@@ -168,8 +168,10 @@ inline int chunk_of(int c) { return c % 16 == 0 ? 16 : (c % 8 == 0 ? 8 : 4); }  
 struct DwPlan { int kind;  /* 0 = VALU (1-channel input / head), 16, 32 */ int cic, coc, th, chunks, npb, tiles; };
 DwPlan dw_plan(const Layer& l, int B) {
     DwPlan p{};
-    if (l.cin % 4 || l.cout % 4 || l.kh == 1) {   // first layer (in_ch not a multiple of 4) and the 1x1 n_cls-wide head
-        p.kind = 0; p.cic = l.cin % 4 ? 1 : chunk_of(l.cin); p.coc = l.cout % 4 ? (l.cout <= 4 ? 4 : 8) : chunk_of(l.cout); p.th = kTileY;
+    if (l.src == SRC_INPUT || l.cin % 4 || l.cout % 4 || l.kh == 1) {
+        // first layer (ANY in_ch: its source is the caller's image, uint8 or f32 -- only the VALU kernel's fetch_x reads
+        // that; the MFMA stagers assume an activation-typed tensor) and the 1x1 n_cls-wide head
+        p.kind = 0; p.cic = (l.src == SRC_INPUT || l.cin % 4) ? 1 : chunk_of(l.cin); p.coc = l.cout % 4 ? (l.cout <= 4 ? 4 : 8) : chunk_of(l.cout); p.th = kTileY;
     } else if (l.cin >= 32 && l.cout >= 32) {
         p.kind = 32; p.cic = l.cin % 64 == 0 ? 64 : 32; p.coc = 32; p.th = p.cic == 64 ? 2 : 4;
     } else {

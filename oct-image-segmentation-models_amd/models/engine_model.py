@@ -348,6 +348,10 @@ class Model:
         4*C B/px).  With ``want_maps`` also the (n, C-1, H, W) uint8 boundary maps of
         ``convert_predictions_to_maps_semantic``, computed on the device from the class maps."""
         x_u8 = np.ascontiguousarray(x_u8)
+        if x_u8.dtype != np.uint8:
+            # the reference normalises x / 255 whatever the dtype (models/unet.py:87-91); the engine's float32 input
+            # path means "already normalised", so do the division here rather than silently skipping it
+            x_u8 = np.ascontiguousarray(x_u8.astype(np.float32) / np.float32(255.0))
         n = x_u8.shape[0]
         eng = self._ensure_engine(min(batch_size, n), False)
         out = np.empty(x_u8.shape[:3], np.uint8)

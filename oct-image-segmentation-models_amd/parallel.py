@@ -87,3 +87,21 @@ def max_over_ranks(value: float, device=None) -> float:
 def barrier() -> None:
     if world_size() > 1:
         dist.barrier()
+
+
+def broadcast_object(obj, src: int = 0):
+    """The same small Python object on every rank (rank ``src``'s copy)."""
+    if world_size() == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def shared_seed(seed: Optional[int]) -> int:
+    """One shuffle / augmentation seed for ALL ranks: every rank must draw the same global batches so that the
+    per-rank slices of ``shard_batch`` partition ONE batch (MirroredStrategy splits one generator's batch).
+    ``seed=None`` (the reference's unseeded shuffle) draws from OS entropy on rank 0 and broadcasts it."""
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1)[0]) if env_rank()[0] == 0 or world_size() == 1 else 0
+    return int(broadcast_object(int(seed)))

@@ -133,7 +133,7 @@ def train_model(training_params: TrainingParams, mlflow_params=None):
     aug_val_mode = training_params.aug_mode if training_params.aug_val else "none"
 
     monitor = training_params.model_save_monitor
-    timestamp = utils.get_timestamp()
+    timestamp = parallel.broadcast_object(utils.get_timestamp())   # one results folder for all ranks
     save_foldername = training_params.results_location / Path(timestamp + "_" + model_architecture)
     if rank == 0:
         os.makedirs(save_foldername, exist_ok=True)
@@ -155,7 +155,9 @@ def train_model(training_params: TrainingParams, mlflow_params=None):
         save_training_params_file(save_foldername, "\n".join(model_summary), model_container.get_config(),
                                   training_dataset_md5, c_weight, timestamp, training_params, optimizer)
 
-    seed = training_params.seed
+    # every rank draws the SAME global batches (its slice of each is taken in Model._device_batch): an unseeded
+    # run gets one OS-entropy seed from rank 0, not one per rank
+    seed = parallel.shared_seed(training_params.seed) if parallel.world_size() > 1 else training_params.seed
     train_gen = data_gen.DataGenerator(train_images, train_labels, batch_size, training_params.aug_fn_args, training_params.aug_mode,
                                        training_params.aug_probs, training_params.aug_fly,
                                        model_container.get_preprocess_input_fn(), seed=seed)

@@ -91,6 +91,22 @@ def test_data_generator_contract():
         DataGenerator(images, labels, 4, [], "one", (), False, None)   # an augmentation mode needs augmentations
 
 
+def test_data_generator_non_uint8_dataset_is_normalised_not_passed_raw():
+    """the reference divides by 255 whatever the dataset dtype; only uint8 may take the device /255 path."""
+    from oct_image_segmentation_models_amd.common.data_generator import DataGenerator
+    rng = np.random.default_rng(3)
+    images = rng.integers(0, 256, (6, 4, 6, 1)).astype(np.float32)      # float32 in [0, 255]
+    labels = rng.integers(0, 3, (6, 4, 6, 1)).astype(np.uint8)
+    g = DataGenerator(images, labels, 2, [], "none", (), False, None, seed=1)
+    assert g.oct_fast_path is False
+    X, _ = g[0]
+    assert X.dtype == np.float32 and X.max() <= 1.0
+    assert np.array_equal(X, images[g.batch_gen.sample_shuffle[:2]] / np.float32(255))
+    with pytest.raises(TypeError):
+        g.next_batch_u8()
+    assert DataGenerator(images.astype(np.uint8), labels, 2, [], "none", (), False, None, seed=1).oct_fast_path is True
+
+
 def test_data_generator_augmentation_modes():
     """'all' / 'one' modes, fly / pre-computed, flip exact, noise within its documented range."""
     from oct_image_segmentation_models_amd.common import augmentation as aug

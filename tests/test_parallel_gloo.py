@@ -69,6 +69,48 @@ def test_dp_two_ranks_equals_mean_of_rank_losses(tmp_path):
     assert abs(r0["loss"] - losses[0]) < 1e-15 and abs(r1["loss"] - losses[1]) < 1e-15
 
 
+def _seed_worker(rank, world, port, tmpdir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oct_image_segmentation_models_amd import parallel
+    from oct_image_segmentation_models_amd.common.data_generator import DataGenerator
+    parallel.init("gloo")
+    seed = parallel.shared_seed(None)              # unseeded run: rank 0's OS-entropy draw, broadcast
+    stamp = parallel.broadcast_object(f"stamp-from-rank-{rank}")
+    rng = np.random.default_rng(0)
+    images = rng.integers(0, 256, (12, 4, 6, 1)).astype(np.uint8)
+    labels = rng.integers(0, 3, (12, 4, 6, 1)).astype(np.uint8)
+    g = DataGenerator(images, labels, 4, [], "none", (), False, None, seed=seed)
+    taken = []
+    for epoch in range(2):
+        for _ in range(len(g)):
+            X, lab = g.next_batch_u8()             # the GLOBAL batch, as Model._device_batch sees it
+            lo, hi = parallel.shard_batch(X.shape[0], rank, world)
+            taken.append(X[lo:hi])
+        g.on_epoch_end()
+    np.savez(os.path.join(tmpdir, f"s{rank}.npz"), seed=seed, taken=np.stack(taken), stamp=stamp)
+    dist.destroy_process_group()
+
+
+def test_dp_ranks_share_one_shuffle_and_partition_each_global_batch(tmp_path):
+    """with seed=None every rank used to shuffle differently, so rank slices duplicated / dropped samples."""
+    port = _free_port()
+    mp.spawn(_seed_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s0 = np.load(tmp_path / "s0.npz"); s1 = np.load(tmp_path / "s1.npz")
+    assert int(s0["seed"]) == int(s1["seed"])
+    assert str(s0["stamp"]) == str(s1["stamp"]) == "stamp-from-rank-0"
+    rng = np.random.default_rng(0)
+    images = rng.integers(0, 256, (12, 4, 6, 1)).astype(np.uint8)
+    key = lambda a: a.reshape(a.shape[0], -1).sum(1).tolist()      # noqa: E731  (image sums identify samples here)
+    assert len(set(key(images))) == 12
+    per_epoch = s0["taken"].shape[0] // 2
+    for e in range(2):
+        got = []
+        for b in range(per_epoch):
+            got += key(s0["taken"][e * per_epoch + b]) + key(s1["taken"][e * per_epoch + b])
+        assert sorted(got) == sorted(key(images))   # 3 global batches of 4 = every sample exactly once per epoch
+
+
 def test_shard_helpers():
     from oct_image_segmentation_models_amd import parallel
     assert [parallel.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
