@@ -104,11 +104,27 @@ int oct_unet_loss_dice(oct_unet* h, float smooth, float* out4_dev, oct_stream_t 
  * losses; class_weight_dev = n_cls device floats or NULL, caller-owned and kept alive).  oct_unet_loss_focal_dice is
  * oct_unet_loss_dice with 8 outputs: out8_dev = out4 + {focal term, w*focal + (1-w)*dice_macro,
  * w*focal + (1-w)*dice_micro, 0}; oct_unet_backward then differentiates the combination chosen by its `macro` flag. */
+/* Unverifiable detail, isolated as a switch (like cfg.bn_unbiased_moving_var): third-party focal-loss==0.0.7 clips the
+ * probabilities to [1e-7, 1-1e-7] for the logarithm; whether its (1 - p_y)^gamma modulation also sees the clipped value
+ * cannot be checked here (package absent).  oct_set_option("focal_clip_modulation", 0) [default]: only the logarithm is
+ * clipped; 1: both.  The two differ only where p_y is outside the clip range, by < 1e-7 relative in the loss and -- after
+ * the softmax Jacobian, which multiplies by p_y -- by < 1e-6 of the gradient scale (tests/test_gpu_parity.py::
+ * test_focal_clip_modulation_switch pins both against the oracle on a saturated head). */
 int oct_unet_set_focal_dice(oct_unet* h, float focal_loss_weight, float gamma, const float* class_weight_dev);
 int oct_unet_loss_focal_dice(oct_unet* h, float smooth, float* out8_dev, oct_stream_t stream);
 /* After training forward + loss_dice: fills the grads buffer with d(loss_scale*loss)/dparams. */
 int oct_unet_backward(oct_unet* h, const unsigned char* labels_dev, int macro, float loss_scale,
                       oct_stream_t stream);
+
+/* ---- data-parallel overlap (reference: tf.distribute.MirroredStrategy, training/training.py:185-188,243) ----
+ * The gradient buffer has the parameter layout (Keras creation order: encoder, bottleneck, decoder, head) and backward
+ * runs head -> decoder -> bottleneck -> encoder.  With a tail event set, oct_unet_backward sums the partial slabs of
+ * every layer from the first bottleneck conv on as soon as that conv's gradients are queued and records the event on
+ * `stream`: floats [oct_unet_grad_tail_offset(cfg), param_count) of grads are final from then on, so the launcher can
+ * all-reduce that segment on a side stream (after hipStreamWaitEvent) while the encoder backward still runs, and the
+ * remaining head segment [0, offset) after backward.  hip_event: a hipEvent_t owned by the caller, NULL disables. */
+int    oct_unet_set_tail_event(oct_unet* h, void* hip_event);
+size_t oct_unet_grad_tail_offset(const oct_unet_cfg* cfg);
 
 /* ---- optimizers on flat buffers (Keras formulations) ---- */
 int oct_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, size_t n,
@@ -160,6 +176,7 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   "pair8_geometry" (NWY*100 + NWX*10 + RPW in {221, 111}, default 221): waves per block (rows x columns)
  *   and 4-row groups per wave of that kernel; its tile is (4*RPW*NWY) x (32*NWX) pixels. */
 int oct_set_option(const char* name, int value);
+int oct_get_option(const char* name, int* value);
 
 /* ---- introspection for tests: device pointer of a layer's saved pre-BN output / gradient ---- */
 /* which: 0 = z, 1 = g (f32 or bf16 per cfg.dtype; max_batch x out_h x out_w x cout);

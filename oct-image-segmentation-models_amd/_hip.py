@@ -64,6 +64,8 @@ SYMBOLS = [
     ("oct_unet_set_focal_dice", C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     ("oct_unet_loss_focal_dice", C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     ("oct_unet_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    ("oct_unet_set_tail_event", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("oct_unet_grad_tail_offset", C.c_size_t, [_P(UNetCfg)]),
     ("oct_adam_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_long, C.c_void_p]),
     ("oct_sgd_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p]),
@@ -75,6 +77,7 @@ SYMBOLS = [
     ("oct_unet_profile_end", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _P(C.c_int)]),
     ("oct_boundary_maps", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("oct_set_option", C.c_int, [C.c_char_p, C.c_int]),
+    ("oct_get_option", C.c_int, [C.c_char_p, _P(C.c_int)]),
     ("oct_unet_debug_activation", C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
     ("oct_last_error", C.c_char_p, []),
     ("oct_version", C.c_char_p, []),
@@ -110,6 +113,12 @@ def lib() -> C.CDLL:
 
 def set_option(name: str, value: int) -> None:
     check(lib().oct_set_option(name.encode(), int(value)), f"oct_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(lib().oct_get_option(name.encode(), C.byref(v)), f"oct_get_option({name})")
+    return int(v.value)
 
 
 def check(rc: int, what: str = "") -> None:

@@ -1,7 +1,7 @@
-"""Result/dataset container I/O.  The reference reads and writes HDF5 through ``h5py``; ``h5py`` is not
-installed in every target environment, so the same key/attribute contract is served by
-``h5py`` when importable and by ``.npz`` files otherwise (a ``foo.hdf5`` request becomes ``foo.hdf5.npz``;
-attributes are stored under ``attr:<name>`` keys)."""
+"""Result/dataset container I/O.  The reference reads and writes HDF5 through ``h5py``; here the same key/attribute
+contract is served, in this order, by ``h5py`` when importable, by ``h5lite`` (this package's ctypes binding of the
+HDF5 C library -- real HDF5 files, present on the build / GPU image) and, only when neither exists, by ``.npz`` files
+(a ``foo.hdf5`` request becomes ``foo.hdf5.npz``; attributes are stored under ``attr:<name>`` keys)."""
 from __future__ import annotations
 
 import os
@@ -12,10 +12,16 @@ import numpy as np
 
 try:  # pragma: no cover - depends on the environment
     import h5py  # type: ignore
-    HAVE_H5PY = True
+    BACKEND = "h5py"
 except Exception:  # noqa: BLE001
-    h5py = None
-    HAVE_H5PY = False
+    from . import h5lite
+    if h5lite.available():
+        h5py = h5lite          # same File / create_dataset / attrs surface, served by libhdf5 through ctypes
+        BACKEND = "h5lite"
+    else:
+        h5py = None
+        BACKEND = "npz"
+HAVE_H5PY = h5py is not None   # "an HDF5 backend exists"
 
 
 def _npz_path(path) -> Path:
@@ -56,8 +62,8 @@ def load(path) -> Dict[str, np.ndarray]:
     npz = path if path.suffix == ".npz" else _npz_path(path)
     if not npz.exists():
         if path.exists():
-            raise RuntimeError(f"{path} is an HDF5 file but h5py is not importable here; convert it to .npz "
-                               "with the same keys")
+            raise RuntimeError(f"{path} is an HDF5 file but neither h5py nor the HDF5 C library is available here; "
+                               "convert it to .npz with the same keys")
         raise FileNotFoundError(str(path))
     with np.load(npz, allow_pickle=False) as z:
         return {k: z[k] for k in z.files}

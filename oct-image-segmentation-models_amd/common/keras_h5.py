@@ -22,9 +22,10 @@ Conv2D -> BatchNormalization, the 1x1 softmax head is the last Conv2D and has no
 built other models first numbers its layers from an offset, so import orders the layers by their numeric suffix
 instead of trusting absolute names.
 
-``h5py`` is needed to touch real files; it is absent from some target environments, so every function takes an
-optional ``h5`` backend (anything with ``File(path, mode)`` returning an h5py-like object) -- the tests inject an
-in-memory stand-in, and without a backend a clear error is raised (no silent fallback).
+Real files are touched through ``h5py`` when importable, else through ``common/h5lite.py`` (libhdf5 via ctypes);
+every function also takes an optional ``h5`` backend (anything with ``File(path, mode)`` returning an h5py-like
+object) -- some tests inject an in-memory stand-in -- and without any backend a clear error is raised (no silent
+fallback).
 """
 from __future__ import annotations
 
@@ -50,9 +51,13 @@ def _backend(h5=None):
     try:
         import h5py  # type: ignore
         return h5py
-    except Exception as e:  # noqa: BLE001
-        raise KerasH5Error("reading or writing Keras .hdf5 checkpoints needs h5py, which is not importable here; "
-                           "use the engine's own .npz checkpoints (Model.save) or install h5py") from e
+    except Exception:  # noqa: BLE001
+        pass
+    from . import h5lite
+    if h5lite.available():       # the HDF5 C library through ctypes: real files without the h5py wheel
+        return h5lite
+    raise KerasH5Error("reading or writing Keras .hdf5 checkpoints needs h5py or the HDF5 C library (libhdf5.so), "
+                       "neither is available here; use the engine's own .npz checkpoints (Model.save)")
 
 
 def conv_plan(config: dict) -> List[Tuple[int, int, int, int, bool]]:
@@ -199,8 +204,10 @@ def read_embedded_config(path, h5=None) -> Optional[dict]:
 
 
 def have_h5py() -> bool:
+    """True when real HDF5 files can be read and written here (h5py, or libhdf5 through ``h5lite``)."""
     try:
         import h5py  # type: ignore  # noqa: F401
         return True
     except Exception:  # noqa: BLE001
-        return False
+        from . import h5lite
+        return h5lite.available()

@@ -229,6 +229,7 @@ struct HeadBwdArgs {
     int HW, nblk, B, macro; float loss_scale; int act_bf16;
     // focal_dice_loss: L = w * focal + (1 - w) * dice  (focal_w = 0: plain Dice)
     float focal_w, focal_gamma; const float* focal_cw; float inv_count;   // inv_count = 1 / (B*H*W)
+    int focal_clip_mod;                // see HeadFwdArgs
 };
 
 template <int C, int CIN, typename AT>
@@ -262,10 +263,15 @@ __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
         for (int c = 0; c < C; ++c) {
             const float yv = lab == c ? 1.f : 0.f;
             dp[c] = -scale * (2.f * yv * den[c] - num[c]) / (den[c] * den[c]);
-            if (fscale != 0.f && lab == c && p[c] >= kFocalEps && p[c] <= 1.f - kFocalEps) {
-                // d/dp [ cw (1-p)^g (-log p) ] = cw ( g (1-p)^(g-1) log p - (1-p)^g / p ); zero where the clip is active
-                const float q = 1.f - p[c], cw = A.focal_cw ? A.focal_cw[c] : 1.f, qg1 = powf(q, A.focal_gamma - 1.f);
-                dp[c] += fscale * cw * (A.focal_gamma * qg1 * logf(p[c]) - qg1 * q / p[c]);
+            if (fscale != 0.f && lab == c) {
+                // d/dp [ cw (1-p)^g (-log pc) ],  pc = clip(p, eps, 1-eps):  cw ( g (1-p)^(g-1) log pc - (1-p)^g / pc * [p == pc] );
+                // with the modulation clipped too (focal_clip_mod) both terms vanish where the clip is active
+                const bool inr = p[c] >= kFocalEps && p[c] <= 1.f - kFocalEps;
+                if (inr || !A.focal_clip_mod) {
+                    const float pc = fminf(fmaxf(p[c], kFocalEps), 1.f - kFocalEps);
+                    const float q = 1.f - p[c], cw = A.focal_cw ? A.focal_cw[c] : 1.f, qg1 = powf(q, A.focal_gamma - 1.f);
+                    dp[c] += fscale * cw * (A.focal_gamma * qg1 * logf(pc) - (inr ? qg1 * q / pc : 0.f));
+                }
             }
             dot = fmaf(p[c], dp[c], dot);
         }

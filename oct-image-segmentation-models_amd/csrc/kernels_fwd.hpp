@@ -287,6 +287,7 @@ struct HeadFwdArgs {
     int HW, nblk, act_bf16;
     // focal half of focal_dice_loss (custom_losses.py:98-178): cw[y] * (1 - p_y)^gamma * (-log p_y), p clipped to [1e-7, 1-1e-7]
     int focal_on; float focal_gamma; const float* focal_cw;   // class weights (C) or nullptr
+    int focal_clip_mod;                // 1: the (1 - p)^gamma modulation also sees the clipped p; 0: only the logarithm does
 };
 constexpr float kFocalEps = 1e-7f;
 
@@ -356,9 +357,9 @@ __global__ __launch_bounds__(kBlock) void head_fwd_k(const HeadFwdArgs A) {
                     float py = p[0];
 #pragma unroll
                     for (int c = 1; c < C; ++c) py = lab == c ? p[c] : py;
-                    py = fminf(fmaxf(py, kFocalEps), 1.f - kFocalEps);
+                    const float pc = fminf(fmaxf(py, kFocalEps), 1.f - kFocalEps);
                     const float cw = A.focal_cw ? A.focal_cw[lab < C ? lab : 0] : 1.f;
-                    v[C * kDiceVals] += cw * powf(1.f - py, A.focal_gamma) * -logf(py);
+                    v[C * kDiceVals] += cw * powf(1.f - (A.focal_clip_mod ? pc : py), A.focal_gamma) * -logf(pc);
                 }
             }
         }

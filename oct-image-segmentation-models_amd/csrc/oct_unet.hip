@@ -29,6 +29,7 @@ int g_igemm_min_blocks = 512;     // a layer takes the taller pixel tile only if
 int g_dwpair8 = 1;                // 3x3 layers with 8 output channels: pixel-pair backward-weights kernel (0 = padded 16-column kernel)
 int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
+int g_focal_clip_mod = 0;          // focal loss: 1 = the (1-p)^gamma modulation sees the clipped p too (see include/oct_unet.h)
 int g_persist_min_tiles = 2048;   // pixel tiles from which thin single-chunk convs use the persistent pipelined kernel
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -203,6 +204,7 @@ struct oct_unet {
     int last_B = 0; int last_training = 0; int have_dice = 0; int dice_final = 0;
     const void* last_x = nullptr; int last_u8 = 0;   // input of the last forward (first layer's dW re-reads it)
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    hipEvent_t tail_event = nullptr;       // recorded in backward once the decoder + bottleneck gradients are final
     Profiler prof;
 };
 
@@ -547,7 +549,7 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
     a.z = last.z; a.ab = last.bn; a.w = h->params + hd.w_off; a.bias = h->params + hd.b_off;
     a.probs = io ? io->probs : nullptr; a.argmax = io ? io->argmax : nullptr; a.labels = io ? io->labels : nullptr;
     a.dice_part = h->dice_part; a.HW = hd.H * hd.W; a.nblk = head_nblk(a.HW, B); a.act_bf16 = h->cfg.dtype;
-    a.focal_on = h->focal_w > 0.f; a.focal_gamma = h->focal_gamma; a.focal_cw = h->focal_cw;
+    a.focal_on = h->focal_w > 0.f; a.focal_gamma = h->focal_gamma; a.focal_cw = h->focal_cw; a.focal_clip_mod = g_focal_clip_mod;
     const int rc = DISPATCH_C(launch_head_fwd, h->cfg.n_cls, a, hd.cin, B, s);
     if (rc) return rc;
     h->last_B = B; h->last_training = training; h->have_dice = a.labels != nullptr;
@@ -567,6 +569,9 @@ int launch_dw(const ConvBwdWArgs& a, int ci_t, int co_t, hipStream_t s, const ch
 #undef DW_CASE
     return fail(-3, "dW: unsupported channel chunking");
 }
+
+// index of the first bottleneck conv: layers [0, idx) are the encoder
+int first_mid_layer(const Plan& pl) { return pl.enc_last.empty() ? 0 : pl.enc_last.back() + 1; }
 
 // register a layer's slabs for the single end-of-backward reduce launch
 void queue_reduce(oct_unet* h, const Layer& l, int npb) {
@@ -680,7 +685,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     hb.z = last.z; hb.bn = last.bn; hb.w = h->params + hd.w_off; hb.bias = h->params + hd.b_off;
     hb.labels = labels; hb.bc = h->dice_bc; hb.g = last.g; hb.part = h->stat_part; hb.wpart = hd.dwp;
     hb.HW = hd.H * hd.W; hb.nblk = head_nblk(hb.HW, B); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale; hb.act_bf16 = h->cfg.dtype;
-    hb.focal_w = h->focal_w; hb.focal_gamma = h->focal_gamma; hb.focal_cw = h->focal_cw; hb.inv_count = 1.f / ((float)B * hb.HW);
+    hb.focal_w = h->focal_w; hb.focal_gamma = h->focal_gamma; hb.focal_cw = h->focal_cw; hb.focal_clip_mod = g_focal_clip_mod; hb.inv_count = 1.f / ((float)B * hb.HW);
     {   // backward-data weights of every block for this step's parameters (one launch)
         ProfScope ps(s, "prep_wt_k", "all", 0, (double)h->wt_total * 8);
         prep_wt_k<<<std::min<unsigned>((h->wt_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wt_descs, h->n_wt, h->wt_total);
@@ -699,6 +704,14 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         if (rc) return rc;
         rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s);
         if (rc) return rc;
+        if (h->tail_event && li == first_mid_layer(pl)) {
+            // every parameter gradient at offsets >= L[li].w_off (bottleneck, decoder, head: Keras creation order) is
+            // final once the queued slabs are summed: the DP launcher all-reduces that segment on a side stream while
+            // the encoder backward runs
+            rc = flush_reduce(h, s);
+            if (rc) return rc;
+            HIP_OK(hipEventRecord(h->tail_event, s));
+        }
         if (l.src == SRC_INPUT) break;
         // backward-data through the MFMA implicit-GEMM kernel: dz (plain) x transposed / effective weights
         int rows = 0;
@@ -977,6 +990,18 @@ int oct_unet_graph_launch(oct_unet* h, oct_stream_t stream) {
     return 0;
 }
 
+int oct_unet_set_tail_event(oct_unet* h, void* hip_event) {
+    if (!h) return fail(-1, "null handle");
+    h->tail_event = (hipEvent_t)hip_event;
+    return 0;
+}
+
+size_t oct_unet_grad_tail_offset(const oct_unet_cfg* c) {
+    if (check_cfg(c)) return 0;
+    const Plan pl = build_plan(*c);
+    return pl.L[first_mid_layer(pl)].w_off;
+}
+
 int oct_unet_profile_begin(oct_unet* h) {
     if (!h) return fail(-1, "null handle");
     for (auto& r : h->prof.recs) { h->prof.pool.push_back(r.e0); h->prof.pool.push_back(r.e1); }
@@ -1017,6 +1042,23 @@ int oct_boundary_maps(const unsigned char* labels, int B, int H, int W, int n_cl
     return 0;
 }
 
+namespace {
+struct Opt { const char* name; int* var; int lo; };
+const Opt k_opts[] = {
+    {"igemm_persistent_min_tiles", &g_persist_min_tiles, 1}, {"dw32_blocks", &g_dw32_blocks, 64},
+    {"dw16_blocks", &g_dw16_blocks, 64}, {"igemm_persistent_blocks", &g_igemm_p_blocks, 8},
+    {"igemm_min_blocks", &g_igemm_min_blocks, 1}, {"dwpair8_enable", &g_dwpair8, 0},
+    {"pair8_geometry", &g_pair_geo, 111}, {"pair8_min_tiles", &g_pair_min_tiles, 1}, {"thin8_min_tiles", &g_thin_min_tiles, 1},
+    {"focal_clip_modulation", &g_focal_clip_mod, 0},
+};
+}  // namespace
+
+int oct_get_option(const char* name, int* value) {
+    if (!name || !value) return fail(-1, "null argument");
+    for (const Opt& o : k_opts) if (!strcmp(name, o.name)) { *value = *o.var; return 0; }
+    return fail(-1, std::string("unknown option: ") + name);
+}
+
 int oct_set_option(const char* name, int value) {
     if (!name) return fail(-1, "null option name");
     if (!strcmp(name, "igemm_persistent_min_tiles")) { g_persist_min_tiles = value < 1 ? 1 : value; return 0; }
@@ -1028,6 +1070,7 @@ int oct_set_option(const char* name, int value) {
     if (!strcmp(name, "pair8_geometry")) { if (value != 221 && value != 111) return fail(-1, "pair8_geometry must be 221 or 111"); g_pair_geo = value; return 0; }
     if (!strcmp(name, "pair8_min_tiles")) { g_pair_min_tiles = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "thin8_min_tiles")) { g_thin_min_tiles = value < 1 ? 1 : value; return 0; }
+    if (!strcmp(name, "focal_clip_modulation")) { g_focal_clip_mod = value ? 1 : 0; return 0; }
     return fail(-1, std::string("unknown option: ") + name);
 }
 

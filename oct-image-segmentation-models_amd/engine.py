@@ -219,6 +219,28 @@ class UNetEngine:
             _hip.check(_hip.lib().oct_sgd_step(self.params.data_ptr(), self.grads.data_ptr(), mom, self.n_params, lr,
                                                momentum, self._stream()), "oct_sgd_step")
 
+    # ---- data-parallel overlap hook ---------------------------------------------------
+    def grad_tail_offset(self) -> int:
+        """First float of the gradient segment (bottleneck + decoder + head) that is final at the tail event."""
+        return int(_hip.lib().oct_unet_grad_tail_offset(C.byref(self.cfg)))
+
+    def set_tail_event(self, event: Optional[torch.cuda.Event]) -> None:
+        """``backward`` records ``event`` on its stream once grads[grad_tail_offset():] are final (None disables)."""
+        if event is not None and not event.cuda_event:
+            with torch.cuda.device(self.device):
+                event.record()          # torch creates the HIP event lazily, at its first record
+        self._tail_event = event        # keep the handle alive
+        _hip.check(_hip.lib().oct_unet_set_tail_event(self._h, C.c_void_p(event.cuda_event) if event is not None else None),
+                   "oct_unet_set_tail_event")
+
+    # ---- arithmetic mode of the convolution kernels (reported by bench.py) --------------------------
+    def mfma_products(self) -> int:
+        """0: the convolutions run on the f32 MFMA pipe.  n > 0: on the bf16 pipe, n bf16 products per product."""
+        return 0
+
+    def mfma_mode_name(self) -> str:
+        return "f32 MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32), f32 accumulate"
+
     # ---- per-launch profiler ---------------------------------------------------------------------
     def profile_begin(self):
         _hip.check(_hip.lib().oct_unet_profile_begin(self._h), "oct_unet_profile_begin")

@@ -268,8 +268,11 @@ class Model:
             eng.forward(x, training=training, labels=lab, want_probs=False)
             loss4 = eng.loss_focal_dice() if focal else eng.loss_dice()
             if training:
-                eng.backward(lab, macro=macro, loss_scale=1.0 / world)
-                parallel.allreduce_gradients(eng.grads)
+                red = getattr(self, "_reducer", None)
+                if red is None or red.engine is not eng:       # _ensure_engine may have built a new engine
+                    red = self._reducer = parallel.GradReducer(eng, overlap=True)
+                # backward + all-reduce (the decoder half on a side stream under the encoder backward)
+                red.backward_and_reduce(lab, macro=macro, loss_scale=1.0 / world)
                 self.optimizer.apply(eng)
             acc = loss4.clone() if acc is None else acc + loss4
         if acc is None:

@@ -300,25 +300,32 @@ def dice_loss_grad(y, p, macro: bool, smooth=1e-5):
 FOCAL_EPS = 1e-7   # keras backend epsilon: the probabilities are clipped to [eps, 1 - eps] before the logarithm
 
 
-def focal_loss_mean(labels, p, gamma=2.0, class_weight=None):
+def focal_loss_mean(labels, p, gamma=2.0, class_weight=None, clip_modulation=False):
     """Focal half of ``SparseCategoricalFocalDiceLoss.call`` (custom_losses.py:98-160): the per-pixel sparse
     categorical focal loss  cw[y] * (1 - p_y)^gamma * (-log p_y)  of the third-party ``focal-loss==0.0.7``
     (``SparseCategoricalFocalLoss``, probabilities clipped to [eps, 1-eps]) summed and divided by the number of label
     elements, custom_losses.py:150-153.  PARITY UNPINNED (third-party package absent; published formula restated)."""
     lab = np.asarray(labels).reshape(p.shape[:-1]).astype(np.int64)
-    py = np.clip(np.take_along_axis(p, lab[..., None], axis=-1)[..., 0], FOCAL_EPS, 1.0 - FOCAL_EPS)
+    raw = np.take_along_axis(p, lab[..., None], axis=-1)[..., 0]
+    py = np.clip(raw, FOCAL_EPS, 1.0 - FOCAL_EPS)
     w = 1.0 if class_weight is None else np.asarray(class_weight, p.dtype)[lab]
-    return float((w * (1.0 - py) ** gamma * -np.log(py)).sum() / lab.size)
+    # ``clip_modulation``: whether (1 - p)^gamma sees the clipped probability too -- unverifiable here (package absent);
+    # the engine exposes the same switch (oct_set_option "focal_clip_modulation", default 0 = logarithm only)
+    return float((w * (1.0 - (py if clip_modulation else raw)) ** gamma * -np.log(py)).sum() / lab.size)
 
 
-def focal_loss_grad(labels, p, gamma=2.0, class_weight=None):
-    """d focal_loss_mean / d p (non-zero only at the true class; zero where the clip is active)."""
+def focal_loss_grad(labels, p, gamma=2.0, class_weight=None, clip_modulation=False):
+    """d focal_loss_mean / d p (non-zero only at the true class).  Where the clip is active the logarithm is constant;
+    with ``clip_modulation`` the modulation is too and the derivative vanishes there."""
     lab = np.asarray(labels).reshape(p.shape[:-1]).astype(np.int64)
     raw = np.take_along_axis(p, lab[..., None], axis=-1)[..., 0]
     py = np.clip(raw, FOCAL_EPS, 1.0 - FOCAL_EPS)
     w = 1.0 if class_weight is None else np.asarray(class_weight, p.dtype)[lab]
-    d = w * (gamma * (1.0 - py) ** (gamma - 1.0) * np.log(py) - (1.0 - py) ** gamma / py) / lab.size
-    d = np.where((raw >= FOCAL_EPS) & (raw <= 1.0 - FOCAL_EPS), d, 0.0)
+    inr = (raw >= FOCAL_EPS) & (raw <= 1.0 - FOCAL_EPS)
+    q = 1.0 - raw
+    d = w * (gamma * q ** (gamma - 1.0) * np.log(py) - np.where(inr, q ** gamma / py, 0.0)) / lab.size
+    if clip_modulation:
+        d = np.where(inr, d, 0.0)
     g = np.zeros_like(p)
     np.put_along_axis(g, lab[..., None], d[..., None], axis=-1)
     return g
@@ -499,7 +506,7 @@ def _maxpool_backward(x, g):
 
 
 def backward(cfg: UNetConfig, params, cache, labels: np.ndarray, macro: bool = True,
-             smooth: float = 1e-5, loss_scale: float = 1.0, focal=None):
+             smooth: float = 1e-5, loss_scale: float = 1.0, focal=None, focal_clip_modulation=False):
     """Hand-derived reverse pass of ``forward(training=True)`` for the Dice losses, or -- with
     ``focal = (focal_loss_weight, gamma, class_weight or None)`` -- for ``focal_dice_loss``.
     Returns (loss, grads) with grads in the same structure as ``params``."""
@@ -510,8 +517,8 @@ def backward(cfg: UNetConfig, params, cache, labels: np.ndarray, macro: bool = T
     dp = dice_loss_grad(y, probs, macro, smooth) * loss_scale
     if focal is not None:
         fw, gamma, cw = focal
-        loss = fw * focal_loss_mean(labels, probs, gamma, cw) + (1.0 - fw) * loss
-        dp = (1.0 - fw) * dp + fw * loss_scale * focal_loss_grad(labels, probs, gamma, cw)
+        loss = fw * focal_loss_mean(labels, probs, gamma, cw, focal_clip_modulation) + (1.0 - fw) * loss
+        dp = (1.0 - fw) * dp + fw * loss_scale * focal_loss_grad(labels, probs, gamma, cw, focal_clip_modulation)
     dz = probs * (dp - (probs * dp).sum(axis=-1, keepdims=True))  # softmax Jacobian
     grads: List[dict] = [dict() for _ in plan]
     g_out: Dict[int, np.ndarray] = {}  # gradient wrt the (activated) output of conv li

@@ -429,6 +429,49 @@ def test_focal_dice_loss_and_gradients_match_oracle(macro, cw):
     assert torch.equal(g0, eng2.grads)
 
 
+@pytest.mark.parametrize("clip_mod", [0, 1])
+def test_focal_clip_modulation_switch(clip_mod):
+    """The one focal-loss detail that cannot be verified here (does (1 - p_y)^gamma see the CLIPPED probability?) is a
+    switch on both sides.  A saturated head (bias +12 / 0 / -12: p_y ~ e^-24 < 1e-7 on class-2 pixels, in range on the others) makes the clip
+    active on most pixels; each setting must match the oracle run with the same setting -- and, the actual finding, the
+    two settings agree with each other far below the test tolerances, because the softmax Jacobian multiplies the
+    differing term by p_y < 1e-7."""
+    from oct_image_segmentation_models_amd import _hip
+    case = CASES[0]
+    B, H, W, C, sn, P, L, ic = case
+    fw, gamma, cw = 0.6, 2.0, (0.5, 2.0, 1.25)
+    cfg, eng, p64, s64 = make(B, H, W, C, sn, P, L, ic, training=True)
+    wl = eng.get_weights()
+    wl[-1] = np.array([12.0, 0.0, -12.0], np.float32)            # head bias: p_2 ~ e^-24 (clipped), p_1 ~ e^-12 (in range)
+    eng.set_weights(wl)
+    p64[-1]["bias"] = wl[-1].astype(np.float64)
+    images, labels = data(B, H, W, C, ic, seed=MARGIN_SEED[case])
+    x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+    eng.set_dropout_step(DROP_STEP)
+    mask = eng.dropout_mask(B).cpu().numpy().astype(np.float64)
+    ref, cache = on.forward(cfg, p64, s64, on.preprocess_u8(images, np.float64), training=True, dropout_mask=mask)
+    py = np.take_along_axis(ref, labels.astype(np.int64), axis=-1)
+    assert (py < 1e-7).mean() > 0.2                                             # the clip really is active
+    _hip.set_option("focal_clip_modulation", clip_mod)
+    try:
+        assert _hip.get_option("focal_clip_modulation") == clip_mod
+        eng.set_focal_dice(fw, gamma, cw)
+        eng.forward(x, training=True, labels=lab, want_probs=False)
+        v = eng.loss_focal_dice().cpu().numpy()
+        eng.backward(lab, macro=True, loss_scale=1.0)
+        g = eng.grads.cpu().numpy().astype(np.float64)
+    finally:
+        _hip.set_option("focal_clip_modulation", 0)
+    focal = on.focal_loss_mean(labels, ref, gamma, cw, clip_modulation=bool(clip_mod))
+    assert abs(v[4] - focal) < 2e-5 * max(1.0, focal), (v[4], focal)
+    both = [on.backward(cfg, p64, cache, labels, macro=True, loss_scale=1.0, focal=(fw, gamma, cw),
+                        focal_clip_modulation=m)[1] for m in (False, True)]
+    gref = on.flatten_grads(both[clip_mod]); gother = on.flatten_grads(both[1 - clip_mod])
+    scale = np.abs(gref).max()
+    assert np.abs(g - gref).max() / scale < 2e-3       # saturated softmax: f32 cancellation in p*(dp - dot) limits this case
+    assert np.abs(gref - gother).max() / scale < 1e-6  # the unverifiable choice cannot move the gradient
+
+
 # ---- bf16 activation storage (BASELINE configs[2]: "bf16 with fp32 BN accum") ---------------------------------
 # dtype=1 keeps every activation / activation-gradient tensor in HBM as bf16 (round-to-nearest-even at the store),
 # while arithmetic, BN statistics, parameters and parameter gradients stay fp32.  Two kinds of gate:
