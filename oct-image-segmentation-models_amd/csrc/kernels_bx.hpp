@@ -1,0 +1,673 @@
+// Implicit-GEMM convolution on the bf16 MFMA pipe of gfx950 (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for layers with
+// >= 32 output channels -- forward convs and backward-data, the same addressing modes and epilogues as
+// kernels_igemm.hpp (reference graph: models/unet.py:26-29,42-47).
+//
+// fp32 mode (NS = 3): every fp32 operand x is split EXACTLY into three bf16 terms x = x0 + x1 + x2 (round-to-nearest
+// residuals: 3 x 8 significant bits = the 24 of an fp32) and a product a*b is formed from the six bf16 products
+//     a0*b0 + a0*b1 + a1*b0 + a0*b2 + a1*b1 + a2*b0          (dropped: a1*b2, a2*b1, a2*b2 <= 2^-25 |a*b|)
+// each of which the matrix core computes exactly and adds into the fp32 accumulator.  The result carries the same
+// ~2^-24 relative error per product as an fp32 FMA chain, at 6 bf16 MFMAs (6 x 32 cycles for 32x32x16) instead of
+// 8 fp32 MFMAs (8 x 64 cycles for the same 32x32x16 block): 2.67x the fp32-pipe rate.
+// bf16 mode (NS = 1, BASELINE configs[2]): activations (after BN + ReLU) and weights are rounded once to bf16 and
+// multiplied directly; accumulation, BN statistics and every epilogue stay fp32.
+//
+// Data movement:
+//  * weights are split / rounded ONCE PER STEP by prep_wbx_k into MFMA A-operand order
+//    [K chunk of 16][M block][tap row][term][tap col][m][16 k] (bf16), so that one (chunk, M block, tap row) slab is a
+//    contiguous run that waves copy global -> LDS with global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip);
+//    two slab slots: the DMA of slab g+1 is in flight while slab g is consumed;
+//  * the input tile of a K chunk goes global -> registers (prefetched one chunk ahead) -> BN + ReLU (+ dropout, concat)
+//    -> split -> LDS image [term][pixel][16 k] (bf16, 32 B per pixel: one ds_read_b128 per B fragment), double
+//    buffered: chunk c+1 is converted and written while the last tap row of chunk c is multiplied;
+//  * one barrier per tap row.  Block = 256 threads = 4 waves, one per SIMD (the tile sizes need most of the LDS);
+//    a wave owns ALL M tiles of the block and TH/4 pixel rows, so A fragments are reused across its pixel tiles and
+//    B fragments across its channel tiles.
+#pragma once
+#include <type_traits>
+
+#include "kernels_bwd.hpp"
+#include "kernels_igemm.hpp"
+
+namespace oct {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_hw{a, b}, bf16x2_hw));
+}
+
+// 8 floats -> NS planes of 8 bf16 (a uint4 each); planes 1 and 2 hold the exact residuals
+template <int NS>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&pl)[NS]) {
+    uint32_t w[NS][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = v[2 * i], b = v[2 * i + 1];
+        const uint32_t p0 = pk_bf16(a, b);
+        w[0][i] = p0;
+        if constexpr (NS > 1) {
+            const float a1 = a - __uint_as_float(p0 << 16), b1 = b - __uint_as_float(p0 & 0xFFFF0000u);
+            const uint32_t p1 = pk_bf16(a1, b1);
+            w[1][i] = p1;
+            if constexpr (NS > 2) {
+                const float a2 = a1 - __uint_as_float(p1 << 16), b2 = b1 - __uint_as_float(p1 & 0xFFFF0000u);
+                w[2][i] = pk_bf16(a2, b2);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NS; ++p) pl[p] = make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
+}
+
+// ---- per-step weight preparation: fp32 [tap][k][m] -> split bf16 slabs in MFMA A-operand order --------------------
+struct WbxDesc {
+    const float* src; bf16_t* dst;
+    int KH, Kc, M, ld;       // src[(tap * Kc + k) * ld + m], k < Kc, m < M
+    int MB, NS;
+    unsigned start, count;   // work items (one per (chunk, mblk, ky, kx, m, k-half)) of this entry in the flattened launch
+};
+
+__global__ __launch_bounds__(kBlock) void prep_wbx_k(const WbxDesc* __restrict__ descs, int nd, unsigned total) {
+    for (unsigned e = blockIdx.x * kBlock + threadIdx.x; e < total; e += gridDim.x * kBlock) {
+        int d = 0;
+        while (d + 1 < nd && e >= descs[d + 1].start) ++d;
+        const WbxDesc D = descs[d];
+        unsigned r = e - D.start;
+        const int kh = r & 1; r >>= 1;
+        const int m = r % D.MB; r /= D.MB;
+        const int kx = r % D.KH; r /= D.KH;
+        const int ky = r % D.KH; r /= D.KH;
+        const int nmb = (D.M + D.MB - 1) / D.MB;
+        const int mb = r % nmb, chunk = r / nmb;
+        const int mg = mb * D.MB + m, tap = ky * D.KH + kx;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = chunk * 16 + kh * 8 + j;
+            v[j] = (k < D.Kc && mg < D.M) ? D.src[((size_t)tap * D.Kc + k) * D.ld + mg] : 0.f;
+        }
+        const size_t slab = ((size_t)chunk * nmb + mb) * D.KH + ky;                 // (chunk, M block, tap row)
+        bf16_t* base = D.dst + slab * ((size_t)D.NS * D.KH * D.MB * 16);
+        const int khs = kh ^ ((m >> 3) & 1);          // bank swizzle of the 32-byte rows (see conv_bx_k)
+        if (D.NS == 3) {
+            uint4 pl[3]; split8<3>(v, pl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<uint4*>(base + (((size_t)p * D.KH + kx) * D.MB + m) * 16 + khs * 8) = pl[p];
+        } else {
+            uint4 pl[1]; split8<1>(v, pl);
+            *reinterpret_cast<uint4*>(base + ((size_t)kx * D.MB + m) * 16 + khs * 8) = pl[0];
+        }
+    }
+}
+
+// bytes of the split weights of one layer direction
+__host__ inline size_t wbx_bytes(int KH, int Kc, int M, int MB, int NS) {
+    return (size_t)((Kc + 15) / 16) * ((M + MB - 1) / MB) * KH * NS * KH * MB * 16 * 2;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// grid (tiles, ceil(Mout/MB), B), block 256.  A.wbx = split weights of this layer direction (prep_wbx_k layout for MB),
+// A.m_off must be a multiple of MB.  DROP: the input passes through dropout (the bottleneck output feeding dec0.up).
+//
+// LDS bank conflicts: a ds_read_b128 is served in groups of 16 lanes over 64 banks; with a 32-byte row pitch rows r and
+// r + 8 (and r + 24) of a group share a 16-byte slot.  Both images therefore store the 8-channel half hh of row r at
+// half-slot hh ^ ((r >> 3) & 1) -- prep_wbx_k swizzles the weights the same way -- which separates every such pair for
+// any tap shift of the pixel rows: conflict-free fragment reads.
+// ------------------------------------------------------------------------------------------------------------------
+template <int KH, int AMODE, int EPI, int TH, int MB, int NS, bool DROP, typename AT>
+__global__ __launch_bounds__(kBlock, 1) void conv_bx_k(const IgemmArgs A) {
+    constexpr int TW = 32, MTW = MB / 32, NTW = TH / 4, ACC = 16, QUADS = 4, MT = 32;
+    static_assert(TH % 4 == 0 && (MB == 32 || MB == 64), "tile geometry");
+    constexpr int IH = AMODE == A_NORMAL ? TH + KH - 1 : (AMODE == A_UPF ? TH / 2 + 1 : 2 * TH + 1);
+    constexpr int IW = AMODE == A_NORMAL ? TW + KH - 1 : (AMODE == A_UPF ? TW / 2 + 1 : 2 * TW + 1);
+    constexpr int NPIX = IH * IW;
+    constexpr int NSLOT = (NPIX * 2 + kBlock - 1) / kBlock;    // staging items (pixel, 8-channel half) per thread
+    constexpr int NPIXP = NSLOT * (kBlock / 2);                // image padded to whole slots: every item has a home, so
+                                                               // the conversion is branch-free (schedulable among MFMAs)
+    constexpr int PLANE_B = NPIXP * 32;                        // bytes of one term's image
+    constexpr int IN_B = NS * PLANE_B;                         // one buffer
+    constexpr int SLAB_B = NS * KH * MB * 32;                  // one (chunk, M block, tap row) weight slab
+    constexpr int PIECES = SLAB_B / 1024;                      // 1 KiB per LDS-DMA wave instruction
+    static_assert(SLAB_B % 1024 == 0, "slab must be a whole number of DMA pieces");
+    constexpr int MAXC = AMODE == A_DOWN2 ? 256 : 512;         // affine rows cached in LDS (K channels; launcher checks)
+    constexpr int EPI_B = EPI == EPI_MASK ? 4 * MB * 4 : MB * 4;
+    constexpr int RED_B = 4 * 2 * MTW * MT * 4;
+    constexpr int SCRATCH_B = (EPI_B + RED_B) > 2 * SLAB_B ? (EPI_B + RED_B) : 2 * SLAB_B;
+
+    __shared__ __attribute__((aligned(1024))) char smem[2 * IN_B + SCRATCH_B + 2 * MAXC * 4];
+    char* const INs = smem;
+    char* const WTs = smem + 2 * IN_B;
+    float* const ABs = reinterpret_cast<float*>(smem + 2 * IN_B + SCRATCH_B);     // [2][MAXC]: a row, b row
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, b = blockIdx.z, m0 = blockIdx.y * MB;
+    const int x0 = (tile % A.tiles_x) * TW, y0 = (tile / A.tiles_x) * TH;
+    const int iy0 = AMODE == A_NORMAL ? y0 - (KH - 1) / 2 : (AMODE == A_UPF ? y0 / 2 : 2 * y0 - 1);
+    const int ix0 = AMODE == A_NORMAL ? x0 - (KH - 1) / 2 : (AMODE == A_UPF ? x0 / 2 : 2 * x0 - 1);
+    const int nch = (A.Cin + 15) / 16;
+    const int nmb = (A.wbx_M + MB - 1) / MB, mblk = (A.m_off + m0) / MB;
+
+    f32x16 acc[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < ACC; ++r) acc[mt][nt][r] = 0.f;
+
+    // ---- weight slabs by LDS-DMA: slab (chunk, ky) -> slot; wave w copies pieces w, w+4, ... ----
+    const char* const wsrc = reinterpret_cast<const char*>(A.wbx);
+    auto dma_slab = [&](int chunk, int ky, int slot) {
+        const char* g = wsrc + (((size_t)chunk * nmb + mblk) * KH + ky) * SLAB_B + lane * 16;
+        char* l = WTs + slot * SLAB_B;
+#pragma unroll
+        for (int p = 0; p < (PIECES + 3) / 4; ++p) {
+            const int piece = wave + 4 * p;
+            if (piece < PIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + piece * 1024),
+                                                 (__attribute__((address_space(3))) void*)(l + piece * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- input staging: item = (tile pixel P, channel half hh); geometry computed once ----
+    int goff[NSLOT], ldst[NSLOT];          // source pixel offset in the image (-1: zero); LDS byte offset of the item
+    const int hh = tid & 1;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        const int P = (tid >> 1) + k * (kBlock / 2), lx = P % IW, ly = P / IW, gy = iy0 + ly, gx = ix0 + lx;
+        const bool in = P < NPIX && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi;
+        goff[k] = in ? gy * A.Wi + gx : -1;
+        ldst[k] = P * 32 + ((hh ^ ((P >> 3) & 1)) * 16);         // P < NPIXP always (pad pixels receive zeros)
+    }
+    const size_t img = (size_t)b * A.Hi * A.Wi;
+    // affine rows of the (possibly concatenated) input, once per block: (a, b) of y = max(a*z + b, lo); identity without BN
+    const bool aff = (A.flags & F_AFF) != 0;
+    const float lo = aff ? 0.f : -3.0e38f;
+    for (int c = tid; c < nch * 16; c += kBlock) {
+        float av = 1.f, bv = 0.f;
+        if (aff && c < A.Cin) {
+            const bool two = (A.flags & F_TWO) && c >= A.C0;
+            const float* ab = two ? A.ab1 : A.ab0; const int C = two ? A.C1 : A.C0, cc = two ? c - A.C0 : c;
+            av = ab[cc]; bv = ab[C + cc];
+        }
+        ABs[c] = av; ABs[MAXC + c] = bv;
+    }
+    typename Raw4<AT>::type pin[NSLOT][2];
+    auto load_in = [&](int c0) {
+        const int c = c0 + 8 * hh;
+        const bool two = (A.flags & F_TWO) && c >= A.C0;
+        const int C = two ? A.C1 : A.C0;
+        const AT* __restrict__ src = (two ? reinterpret_cast<const AT*>(A.x1) + (c - A.C0) : reinterpret_cast<const AT*>(A.x0) + c) + img * C;
+        const bool cok = c < A.Cin;           // channel counts are multiples of 8 on this path
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            const bool ok = cok && goff[k] >= 0;
+            const AT* p = src + (size_t)(ok ? goff[k] : 0) * C;
+            pin[k][0] = ok ? ldraw4<AT>(p) : raw_zero4<AT>();
+            pin[k][1] = ok ? ldraw4<AT>(p + 4) : raw_zero4<AT>();
+        }
+    };
+    // per-chunk constants of the conversion (set by begin_store, used by store_slot): branch-free so that the
+    // conversion of slot k can be scheduled between the MFMAs of a tap
+    float fa[8], fb[8]; bool cok_s = false; int el_c = 0, el_C = 1;
+    auto begin_store = [&](int c0) {
+        const int c = c0 + 8 * hh;
+        cok_s = c < A.Cin;
+        const float4 a0 = ld4(ABs + c), a1 = ld4(ABs + c + 4), b0 = ld4(ABs + MAXC + c), b1 = ld4(ABs + MAXC + c + 4);
+        fa[0] = a0.x; fa[1] = a0.y; fa[2] = a0.z; fa[3] = a0.w; fa[4] = a1.x; fa[5] = a1.y; fa[6] = a1.z; fa[7] = a1.w;
+        fb[0] = b0.x; fb[1] = b0.y; fb[2] = b0.z; fb[3] = b0.w; fb[4] = b1.x; fb[5] = b1.y; fb[6] = b1.z; fb[7] = b1.w;
+        if constexpr (DROP) {
+            const bool two = (A.flags & F_TWO) && c >= A.C0;
+            el_C = two ? A.C1 : A.C0; el_c = two ? c - A.C0 : c;
+        }
+    };
+    auto store_slot = [&](int k, int buf) {
+        const float4 v0 = widen4(pin[k][0]), v1 = widen4(pin[k][1]);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const bool in = cok_s && goff[k] >= 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {        // zero padding is applied AFTER the activation: out-of-image stays 0
+            const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);
+            v[i] = in ? y : 0.f;
+        }
+        if constexpr (DROP) {
+            if (in) {
+                const uint32_t el = (uint32_t)((img + goff[k]) * el_C + el_c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] *= drop_mul(A.drop, el + i);
+            }
+        }
+        uint4 pl[NS];
+        split8<NS>(v, pl);
+        char* d = INs + buf * IN_B + ldst[k];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * PLANE_B) = pl[p];
+    };
+
+    // per-lane pixel offsets (in pixels of the tile image) of the B operand for each of this wave's pixel rows
+    int boff[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int r = wave * NTW + nt;
+        boff[nt] = AMODE == A_NORMAL ? r * IW + j : (AMODE == A_UPF ? 0 : (2 * r) * IW + 2 * j);
+    }
+    const int a_lane = j * 32 + ((h ^ ((j >> 3) & 1)) * 16);    // A fragment: row j of an M tile, swizzled half
+
+    struct Frag { bf16x8 a[MTW][NS], b[NTW][NS]; };
+    // ---- one tap row: KH taps x MTW x NTW output tiles x (6 | 1) bf16 MFMAs; the fragments of tap kx+1 are read while
+    // the MFMAs of tap kx issue; with STORE the next chunk's input slots are converted in the MFMAs' shadow ----
+    auto sweep_row = [&](int ky, int slot, int buf, auto do_store, int sbuf) {
+        const char* Wb = WTs + slot * SLAB_B + a_lane;
+        const char* Ib = INs + buf * IN_B;
+        auto load_frag = [&](int kx, Frag& f) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    f.a[mt][p] = *reinterpret_cast<const bf16x8*>(Wb + ((p * KH + kx) * MB + mt * 32) * 32);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                int off;
+                if constexpr (AMODE == A_UPF) {
+                    const int r = wave * NTW + nt;
+                    off = ((r + ky) >> 1) * IW + ((j + kx) >> 1);
+                } else {
+                    off = boff[nt] + ky * IW + kx;
+                }
+                const char* q = Ib + off * 32 + ((h ^ ((off >> 3) & 1)) * 16);
+#pragma unroll
+                for (int p = 0; p < NS; ++p) f.b[nt][p] = *reinterpret_cast<const bf16x8*>(q + p * PLANE_B);
+            }
+        };
+        auto mfma_tap = [&](const Frag& f) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    f32x16 c = acc[mt][nt];
+                    if constexpr (NS == 3) {     // smallest terms first
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mt][0], f.b[nt][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mt][2], f.b[nt][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mt][1], f.b[nt][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mt][0], f.b[nt][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mt][1], f.b[nt][0], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mt][0], f.b[nt][0], c, 0, 0, 0);
+                    acc[mt][nt] = c;
+                }
+        };
+        Frag f[2];
+        load_frag(0, f[0]);
+#pragma unroll
+        for (int kx = 0; kx < KH; ++kx) {
+            if (kx + 1 < KH) load_frag(kx + 1, f[(kx + 1) & 1]);
+            mfma_tap(f[kx & 1]);
+            if constexpr (decltype(do_store)::value) {
+#pragma unroll
+                for (int k = kx; k < NSLOT; k += KH) store_slot(k, sbuf);
+            }
+        }
+    };
+
+    // ---- pipeline over (chunk, tap row) ----
+    dma_slab(0, 0, 0);
+    load_in(0);
+    __syncthreads();                 // ABs visible
+    begin_store(0);
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) store_slot(k, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                 // image 0 + slab (0,0) landed
+    int g = 0;
+    for (int c = 0; c < nch; ++c) {
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky, ++g) {
+            const bool last_row = ky == KH - 1, more = c + 1 < nch;
+            if (!last_row) dma_slab(c, ky + 1, (g + 1) & 1);
+            else if (more) dma_slab(c + 1, 0, (g + 1) & 1);
+            if (ky == 0 && more) load_in((c + 1) * 16);
+            if (last_row && more) {
+                begin_store((c + 1) * 16);
+                sweep_row(ky, g & 1, c & 1, std::true_type{}, (c + 1) & 1);
+            } else {
+                sweep_row(ky, g & 1, c & 1, std::false_type{}, 0);
+            }
+            // an LDS-DMA becomes visible to other waves' ds_reads only through the issuing wave's vmcnt wait followed by
+            // a barrier: drain explicitly (hipcc also does before __syncthreads() while a DMA is in flight)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (same forms as conv_igemm_k; the weight slots are free now) ----
+    float* const epi = reinterpret_cast<float*>(WTs);
+    float* const red = reinterpret_cast<float*>(WTs + EPI_B);
+    if constexpr (EPI == EPI_FWD) {
+        for (int e = tid; e < MB; e += kBlock) epi[e] = m0 + e < A.Mout ? A.bias[A.m_off + m0 + e] : 0.f;
+    } else if constexpr (EPI == EPI_MASK) {
+        for (int e = tid; e < 4 * MB; e += kBlock) {
+            const int arr = e / MB, m = m0 + e % MB;
+            epi[e] = m < A.Mout ? A.bnin[arr * A.Mout + m] : 0.f;
+        }
+    }
+    typename Raw4<AT>::type zraw[EPI == EPI_MASK ? NTW : 1][EPI == EPI_MASK ? MTW : 1][EPI == EPI_MASK ? QUADS : 1];
+    if constexpr (EPI == EPI_MASK) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int y = y0 + wave * NTW + nt, x = x0 + j;
+            const bool pvalid = y < A.Ho && x < A.Wo;
+            const size_t pix = pvalid ? ((size_t)b * A.Ho + y) * A.Wo + x : 0;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int q = 0; q < QUADS; ++q) {
+                    const int m = m0 + mt * MT + 8 * q + 4 * h;
+                    zraw[nt][mt][q] = (pvalid && m < A.Mout) ? ldraw4<AT>(reinterpret_cast<const AT*>(A.zin) + pix * A.Mout + m) : raw_zero4<AT>();
+                }
+        }
+    }
+    __syncthreads();
+    float s1[MTW][ACC], s2[MTW][ACC];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < ACC; ++r) { s1[mt][r] = 0.f; s2[mt][r] = 0.f; }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int y = y0 + wave * NTW + nt, x = x0 + j;
+        const bool pvalid = y < A.Ho && x < A.Wo;
+        const size_t pix = pvalid ? ((size_t)b * A.Ho + y) * A.Wo + x : 0;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+            for (int q = 0; q < QUADS; ++q) {
+                const int ml = mt * MT + 8 * q + 4 * h, m = m0 + ml;
+                const bool valid = pvalid && m < A.Mout;
+                float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                if constexpr (EPI == EPI_FWD) {
+                    if (valid) {
+                        const float4 bs = ld4(epi + ml);
+                        v[0] += bs.x; v[1] += bs.y; v[2] += bs.z; v[3] += bs.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float u = valid ? v[k] : 0.f;
+                        s1[mt][4 * q + k] += u; s2[mt][4 * q + k] += u * u;
+                    }
+                } else if constexpr (EPI == EPI_MASK) {
+                    const float4 zq = widen4(zraw[nt][mt][q]);
+                    const float zz[4] = {zq.x, zq.y, zq.z, zq.w};
+                    const float4 ea = ld4(epi + BN_A * MB + ml), eb = ld4(epi + BN_B * MB + ml);
+                    const float4 em = ld4(epi + BN_MEAN * MB + ml), er = ld4(epi + BN_RSTD * MB + ml);
+                    const float ka[4] = {ea.x, ea.y, ea.z, ea.w}, kb[4] = {eb.x, eb.y, eb.z, eb.w};
+                    const float km[4] = {em.x, em.y, em.z, em.w}, kr[4] = {er.x, er.y, er.z, er.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int cc = valid ? m + k : 0;
+                        const float yv = fmaf(ka[k], zz[k], kb[k]);
+                        float gv = v[k];
+                        if (A.drop_out) gv *= drop_mul(A.drop, (uint32_t)(pix * A.Mout + cc));
+                        gv = (valid && yv > 0.f) ? gv : 0.f;
+                        const float xh = (zz[k] - km[k]) * kr[k];
+                        v[k] = gv; s1[mt][4 * q + k] += gv; s2[mt][4 * q + k] += gv * xh;
+                    }
+                }
+                if (valid) sta4<AT>(reinterpret_cast<AT*>(A.out) + pix * A.Mout + m, make_float4(v[0], v[1], v[2], v[3]));
+            }
+        }
+    }
+    if constexpr (EPI != EPI_RAW) {
+        if (A.part) {
+            // lanes sharing h hold the same 16 channels of an M tile for 32 different pixels: reduce over the pixel lanes
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                subgroup_reduce_rec<ACC, ACC, 16>(s1[mt], lane);
+                subgroup_reduce_rec<ACC, ACC, 16>(s2[mt], lane);
+                const int ci = sub_chan<ACC, 16>(lane);
+                const int mloc = 8 * (ci >> 2) + 4 * h + (ci & 3);
+                red[((wave * 2 + 0) * MTW + mt) * MT + mloc] = s1[mt][0];
+                red[((wave * 2 + 1) * MTW + mt) * MT + mloc] = s2[mt][0];
+            }
+            __syncthreads();
+            if (tid < 2 * MB) {
+                const int stat = tid / MB, ml = tid % MB, mt = ml / MT, mloc = ml % MT;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s += red[((w * 2 + stat) * MTW + mt) * MT + mloc];
+                if (m0 + ml < A.Mout)
+                    A.part[((size_t)b * A.tiles + tile) * (2 * A.Mout) + (size_t)stat * A.Mout + m0 + ml] = s;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward-weights on the bf16 pipe:  dW[tap][ci][co] = sum_pixels X(pixel + tap)[ci] * dz(pixel)[co]  for layers with
+// >= 32 input and >= 32 output channels (reference: the gradient of models/unet.py:26-29 that Keras' autodiff forms).
+//   MFMA rows (M) = 32 input channels, columns (N) = 32 output channels, K = 16 consecutive pixels of an image row.
+//   Both operands want K (pixels) contiguous per lane while the natural images are channel-fastest:
+//   ds_read_b64_tr_b16 (transposing LDS read, 4 pixels x 16 channels per 16 lanes) delivers exactly that from the
+//   NHWC images [term][pixel][32 channels] (64 B per pixel: the 32 lanes of a read cover 256 contiguous bytes --
+//   conflict-free), for X at any tap offset because a tap shifts whole pixels.
+//   X and dz are split into NS bf16 terms each while they are staged (6 products per fp32 product, see conv_bx_k).
+// Block (256 threads, 1 per CU) = one (32 ci, 32 co) pair for a strided list of 4-row x 32-pixel tiles; wave w owns
+// pixel row w of every tile and all taps (9 accumulator tiles); global loads run two tiles ahead in registers, the
+// LDS images are double buffered (the split of tile t+1 is written while tile t is multiplied), one barrier per tile;
+// a fixed-order 4-wave sum through LDS at the end writes ONE partial slab per block (reduce_all_k sums the slabs).
+// UP: the conv input is the nearest-upsampled low-res tensor (2x2 up-conv): the VIRTUAL high-res tile is staged.
+// grid (npb, Cin/32, Cout/32); A.tiles / A.tiles_x for 4 x 32 tiles.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int KH, bool UP, int NS, typename AT>
+__global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
+    constexpr int TH = 4, TW = 32, TAPS = KH * KH;
+    constexpr int IH = UP ? TH + 1 : TH + KH - 1, IW = UP ? TW + 1 : TW + KH - 1, PT = UP ? 0 : (KH - 1) / 2;
+    constexpr int NPX = IH * IW, NPD = TH * TW;
+    constexpr int NXS = (NPX * 4 + kBlock - 1) / kBlock, NDS = (NPD * 4) / kBlock;     // staging items per thread
+    constexpr int NPXP = NXS * (kBlock / 4);                    // X image padded to whole slots (branch-free staging)
+    constexpr int XPL = NPXP * 64, DPL = NPD * 64;              // bytes of one term's image (32 channels x bf16 per pixel)
+    constexpr int BUF_B = NS * (XPL + DPL);
+    static_assert((NPD * 4) % kBlock == 0, "dz tile items");
+    constexpr int RED_B = 4 * 16 * 64 * 4;                      // one tap's 4-wave sum
+    static_assert(2 * BUF_B >= RED_B + kBlock * 8 * 4, "scratch fits in the image buffers");
+    __shared__ __attribute__((aligned(256))) char smem[2 * BUF_B];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    const int Hs = UP ? A.H >> 1 : A.H, Ws = UP ? A.W >> 1 : A.W;
+
+    // ---- staging set-up: a thread always serves channel octet o = tid & 3 of X and of dz (Cin, Cout multiples of 32) ----
+    const int o8 = 8 * (tid & 3);
+    const int cx = ci0 + o8;
+    const bool two = (A.flags & F_TWO) && cx >= A.C0;
+    const int Cs = two ? A.C1 : A.C0, ccx = two ? cx - A.C0 : cx;
+    const AT* __restrict__ xsrc = (two ? reinterpret_cast<const AT*>(A.x1) : reinterpret_cast<const AT*>(A.x0)) + ccx;
+    const AT* __restrict__ dsrc = reinterpret_cast<const AT*>(A.dz) + co0 + o8;
+    const bool aff = (A.flags & F_AFF) != 0;
+    const float lo = aff ? 0.f : -3.0e38f;
+    float fa[8], fb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa[i] = 1.f; fb[i] = 0.f; }
+    if (aff) {
+        const float* ab = two ? A.ab1 : A.ab0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { fa[i] = ab[ccx + i]; fb[i] = ab[Cs + ccx + i]; }
+    }
+    int xly[NXS], xlx[NXS];
+#pragma unroll
+    for (int k = 0; k < NXS; ++k) {
+        const int P = (tid >> 2) + k * (kBlock / 4);
+        xly[k] = P < NPX ? P / IW : -1000000; xlx[k] = P % IW;      // pad pixels fall outside every image -> zeros
+    }
+    struct Regs { typename Raw4<AT>::type x[NXS][2], d[NDS][2]; };
+    float bsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+
+    auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
+        b = tl / A.tiles; const int t = tl % A.tiles;
+        x0 = (t % A.tiles_x) * TW; y0 = (t / A.tiles_x) * TH;
+    };
+    // Loads are UNCONDITIONAL (addresses clamped into the image; out-of-image values are discarded by store()): no
+    // exec-mask branches, so staging and the MFMA loop share one basic block and the compiler interleaves them.
+    auto load = [&](int tl, Regs& R) {
+        int b, y0, x0; tile_of(tl, b, y0, x0);
+#pragma unroll
+        for (int k = 0; k < NXS; ++k) {
+            int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;             // position in the conv-input (high-res) image
+            gy = gy < 0 ? 0 : (gy >= A.H ? A.H - 1 : gy); gx = gx < 0 ? 0 : (gx >= A.W ? A.W - 1 : gx);
+            const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
+            const AT* p = xsrc + (((size_t)b * Hs + sy) * Ws + sx) * Cs;
+            R.x[k][0] = ldraw4<AT>(p); R.x[k][1] = ldraw4<AT>(p + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NDS; ++k) {
+            const int P = (tid >> 2) + k * (kBlock / 4);
+            int py = y0 + P / TW, px = x0 + P % TW;
+            py = py >= A.H ? A.H - 1 : py; px = px >= A.W ? A.W - 1 : px;
+            const AT* p = dsrc + (((size_t)b * A.H + py) * A.W + px) * A.Cout;
+            R.d[k][0] = ldraw4<AT>(p); R.d[k][1] = ldraw4<AT>(p + 4);
+        }
+    };
+    // `live`: false for the dummy store issued behind the last tile (keeps the loop body branch-free)
+    auto store = [&](int tl, const Regs& R, int buf, bool live) {
+        int b, y0, x0; tile_of(tl, b, y0, x0);
+        char* const Xb = smem + buf * BUF_B + o8 * 2;
+        char* const Db = smem + buf * BUF_B + NS * XPL + o8 * 2;
+#pragma unroll
+        for (int k = 0; k < NXS; ++k) {
+            const float4 v0 = widen4(R.x[k][0]), v1 = widen4(R.x[k][1]);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;
+            const bool in = gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {      // out-of-range stays exactly zero (padding is applied after the activation)
+                const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);
+                v[i] = in ? y : 0.f;
+            }
+            if (A.flags & F_DROP) {            // (only the up-conv behind the bottleneck: a uniform, rarely taken branch)
+                const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
+                const uint32_t el = (uint32_t)((((size_t)b * Hs + sy) * Ws + sx) * Cs + ccx);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = in ? v[i] * drop_mul(A.drop, el + i) : 0.f;
+            }
+            uint4 pl[NS];
+            split8<NS>(v, pl);
+            const int P = (tid >> 2) + k * (kBlock / 4);
+            char* d = Xb + P * 64;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * XPL) = pl[p];
+        }
+#pragma unroll
+        for (int k = 0; k < NDS; ++k) {
+            const int P = (tid >> 2) + k * (kBlock / 4);
+            const bool in = live && y0 + P / TW < A.H && x0 + P % TW < A.W;
+            const float4 v0 = widen4(R.d[k][0]), v1 = widen4(R.d[k][1]);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[i] = in ? v[i] : 0.f; bsum[i] += v[i]; }
+            uint4 pl[NS];
+            split8<NS>(v, pl);
+#pragma unroll
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(Db + P * 64 + p * DPL) = pl[p];
+        }
+    };
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposing-read lane offsets: 16-lane group g reads the 4 pixels x 16 channels block at pixel rows 8h + 4t + q,
+    // channels 16 (g & 1) + 4 p  (h = lane >> 5, q = (lane & 15) >> 2, p = lane & 3); lane gets channel lane & 31
+    const int laneoff = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    auto tr8 = [&](const char* base) -> bf16x8 {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * 64));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto compute = [&](int buf) {
+        const char* Xl = smem + buf * BUF_B + laneoff;
+        const char* Dl = smem + buf * BUF_B + NS * XPL + laneoff + (wave * TW) * 64;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < TW / 16; ++ks) {
+            bf16x8 bv[NS];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) bv[p] = tr8(Dl + p * DPL + ks * 16 * 64);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int ky = t / KH, kx = t % KH;
+                bf16x8 a[NS];
+#pragma unroll
+                for (int p = 0; p < NS; ++p) a[p] = tr8(Xl + p * XPL + ((wave + ky) * IW + ks * 16 + kx) * 64);
+                f32x16 c = acc[t];
+                if constexpr (NS == 3) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bv[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bv[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bv[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bv[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bv[0], c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bv[0], c, 0, 0, 0);
+                acc[t] = c;
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- tile pipeline: tile t in LDS buffer `buf`, tile t+1 in registers, tile t+2 requested; per iteration ONE
+    // branch-free body: convert + write t+1 into the other buffer, request t+2, multiply t -- then one barrier ----
+    Regs R;
+    const int t0 = blockIdx.x, step = A.npb, tend = A.total_tiles, tlast = tend - 1;
+    if (t0 < tend) {
+        load(t0, R);
+        store(t0, R, 0, true);
+        load(t0 + step < tend ? t0 + step : tlast, R);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int tl = t0; tl < tend; tl += step, buf ^= 1) {
+        const int t1 = tl + step, t2 = tl + 2 * step;
+        store(t1 < tend ? t1 : tlast, R, buf ^ 1, t1 < tend);
+        load(t2 < tend ? t2 : tlast, R);
+        compute(buf);
+        __syncthreads();
+    }
+
+    // ---- 4-wave sum, tap by tap, through LDS (fixed order), then the slab; bias gradient = column sums of dz ----
+    float* const red = reinterpret_cast<float*>(smem);
+    const size_t wsize = (size_t)TAPS * A.Cin * A.Cout;
+    float* out = A.part + (size_t)blockIdx.x * (wsize + A.Cout);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+        for (int idx = tid; idx < 16 * 64; idx += kBlock) {
+            const int r = idx / 64, ln = idx % 64;
+            const float s = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+            const int col = ln & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+            if (ci0 + row < A.Cin && co0 + col < A.Cout)
+                out[((size_t)t * A.Cin + ci0 + row) * A.Cout + co0 + col] = s;
+        }
+    }
+    __syncthreads();
+    float* const bs = red + 4096;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bs[tid * 8 + i] = bsum[i];
+    __syncthreads();
+    if (tid < 32 && blockIdx.y == 0 && co0 + tid < A.Cout) {
+        const int oct = tid >> 3, comp = tid & 7;
+        float s = 0.f;
+        for (int t = oct; t < kBlock; t += 4) s += bs[t * 8 + comp];
+        out[wsize + co0 + tid] = s;
+    }
+}
+
+}  // namespace oct

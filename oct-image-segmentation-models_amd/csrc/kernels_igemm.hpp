@@ -41,6 +41,8 @@ struct IgemmArgs {
     int act_bf16;                                // activation storage type selector for the launchers
     int drop_out;                                // EPI_MASK: the producer's output passes through dropout
     DropCfg drop;
+    const void* wbx; int wbx_M;                  // bf16-pipe kernels (kernels_bx.hpp): split weights of this layer direction
+                                                 // in prep_wbx_k layout, and the total M the layout was built for
 };
 
 template <int SHAPE> struct MfmaShape;

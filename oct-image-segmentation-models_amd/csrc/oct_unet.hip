@@ -16,6 +16,7 @@
 #include "kernels_dw.hpp"
 #include "kernels_thin.hpp"
 #include "kernels_pair.hpp"
+#include "kernels_bx.hpp"
 
 using namespace oct;
 
@@ -29,6 +30,10 @@ int g_igemm_min_blocks = 512;     // a layer takes the taller pixel tile only if
 int g_dwpair8 = 1;                // 3x3 layers with 8 output channels: pixel-pair backward-weights kernel (0 = padded 16-column kernel)
 int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
+int g_dwbx_blocks = 256;           // target grid of a bf16-pipe backward-weights launch (1 block per CU: the kernel needs most of the LDS)
+int g_bx_min_blocks = 256;         // a bf16-pipe launch takes the taller pixel tile only if that still yields this many blocks
+int g_mfma_mode = 1;               // 1: convs with >= 32 output channels run on the bf16 MFMA pipe (kernels_bx.hpp: 6 split products
+                                  //    in fp32 mode, 1 in bf16 mode); 0: the fp32-pipe kernels everywhere
 int g_focal_clip_mod = 0;          // focal loss: 1 = the (1-p)^gamma modulation sees the clipped p too (see include/oct_unet.h)
 int g_persist_min_tiles = 2048;   // pixel tiles from which thin single-chunk convs use the persistent pipelined kernel
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -80,6 +85,7 @@ struct Layer {
     float* dwp = nullptr;  // this layer's dW slabs [npb][kh*kw*cin*cout + cout]
     int dw_rows = 0;       // slabs allocated at creation: a launch never uses more (tuning options may change later)
     float* wt = nullptr;   // backward-data weights: transposed+flipped 3x3, or effective 3x3 of an up-conv (9*cin*cout)
+    bf16_t* wbx_f = nullptr; bf16_t* wbx_b = nullptr;   // split weights for the bf16-pipe kernels (forward / backward-data)
 };
 
 struct Plan {
@@ -165,10 +171,25 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int tiles_of(int H, int W) { return cdiv(H, kTileY) * cdiv(W, kTileX); }
 inline int chunk_of(int c) { return c % 16 == 0 ? 16 : (c % 8 == 0 ? 8 : 4); }   // channel chunk per thread
 
+// ---- bf16-pipe kernel eligibility (kernels_bx.hpp): forward needs >= 32 output channels, backward-data >= 32 channels
+// per launch (a concat's dX is two launches of cin/2 channels each); K channels in multiples of 8, <= 512 ----
+inline int bx_mb(int M) { return M % 64 == 0 ? 64 : 32; }
+inline bool bx_fwd_ok(const Layer& l) { return l.src != SRC_INPUT && l.has_bn && l.cin % 8 == 0 && l.cin <= 512 && l.cout % 32 == 0; }
+inline int bx_bwd_cg(const Layer& l) { return l.src == SRC_CONCAT ? l.cin / 2 : l.cin; }
+inline bool bx_bwd_ok(const Layer& l) { return l.src != SRC_INPUT && l.has_bn && l.cout % 8 == 0 && l.cout <= 512 && bx_bwd_cg(l) % 32 == 0; }
+
 // dW plan: which kernel handles a layer, its channel chunking, pixel-tile height and pixel-block count
-struct DwPlan { int kind;  /* 0 = VALU (1-channel input / head), 16, 32 */ int cic, coc, th, chunks, npb, tiles; };
-DwPlan dw_plan(const Layer& l, int B) {
+struct DwPlan { int kind;  /* 0 = VALU (1-channel input / head), 16, 32, 33 = bf16 pipe (conv_dwbx_k) */ int cic, coc, th, chunks, npb, tiles; };
+DwPlan dw_plan(const Layer& l, int B, int mfma_mode) {
     DwPlan p{};
+    if (mfma_mode && l.src != SRC_INPUT && l.kh != 1 && l.cin % 32 == 0 && l.cout % 32 == 0) {
+        // wide layers on the bf16 pipe: one block per (32 ci, 32 co) pair and pixel slice, ~1 block per CU in total
+        p.kind = 33; p.cic = 32; p.coc = 32; p.th = 4;
+        p.chunks = (l.cin / 32) * (l.cout / 32);
+        p.tiles = cdiv(l.H, p.th) * cdiv(l.W, kTileX);
+        p.npb = std::max(1, std::min(B * p.tiles, cdiv(g_dwbx_blocks, p.chunks)));
+        return p;
+    }
     if (l.src == SRC_INPUT || l.cin % 4 || l.cout % 4 || l.kh == 1) {
         // first layer (ANY in_ch: its source is the caller's image, uint8 or f32 -- only the VALU kernel's fetch_x reads
         // that; the MFMA stagers assume an activation-typed tensor) and the 1x1 n_cls-wide head
@@ -200,6 +221,7 @@ struct oct_unet {
     float* dice_part = nullptr; double* dice_bc = nullptr; float* loss4 = nullptr;   // loss4: 8 floats (dice_finalize_k)
     float focal_w = 0.f, focal_gamma = 2.f; const float* focal_cw = nullptr;           // focal_dice_loss (0 = plain Dice)
     WtDesc* wt_descs = nullptr; int n_wt = 0; unsigned wt_total = 0;
+    WbxDesc* wbx_descs = nullptr; int n_wbx_f = 0, n_wbx_b = 0; unsigned wbx_f_total = 0, wbx_b_total = 0;   // [fwd..., bwd...]
     unsigned long long drop_step = 0; int drop_advance = 0;
     int last_B = 0; int last_training = 0; int have_dice = 0; int dice_final = 0;
     const void* last_x = nullptr; int last_u8 = 0;   // input of the last forward (first layer's dW re-reads it)
@@ -222,12 +244,16 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
         void* g = c.training && l.has_bn ? (void*)take(n * esz) : nullptr;
         float* bn = l.has_bn ? (float*)take((size_t)BN_ARRAYS * l.cout * 4) : nullptr;
         float* wt = (c.training && l.has_bn && l.src != SRC_INPUT) ? (float*)take((size_t)9 * l.cin * l.cout * 4) : nullptr;
-        if (base) { l.z = z; l.g = g; l.bn = bn; l.wt = wt; }
+        const int ns = c.dtype ? 1 : 3;
+        bf16_t* wf = bx_fwd_ok(l) ? (bf16_t*)take(wbx_bytes(l.kh, l.cin, l.cout, bx_mb(l.cout), ns)) : nullptr;
+        bf16_t* wb = (c.training && bx_bwd_ok(l)) ? (bf16_t*)take(wbx_bytes(3, l.cout, l.cin, bx_mb(bx_bwd_cg(l)), ns)) : nullptr;
+        if (base) { l.z = z; l.g = g; l.bn = bn; l.wt = wt; l.wbx_f = wf; l.wbx_b = wb; }
         // statistic partial rows: one per pixel tile; the MFMA kernels may use tiles as small as 2 x 32 pixels
         stat_max = std::max(stat_max, B * cdiv(l.H, 2) * cdiv(l.W, kTileX) * 2 * (size_t)std::max(l.cout, l.cin));
         if (c.training) {
             const size_t wsz = (size_t)l.kh * l.kw * l.cin * l.cout + l.cout;
-            const size_t rows = l.src == SRC_HEAD ? (size_t)(2048 + c.max_batch) : (size_t)dw_plan(l, c.max_batch).npb;
+            const size_t rows = l.src == SRC_HEAD ? (size_t)(2048 + c.max_batch)
+                                                  : (size_t)std::max(dw_plan(l, c.max_batch, 0).npb, dw_plan(l, c.max_batch, 1).npb);
             float* dwp = (float*)take(rows * wsz * 4);
             if (base) { l.dwp = dwp; l.dw_rows = (int)rows; }
             dw_max = 0;
@@ -246,7 +272,8 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
     double* bc = (double*)take((B * 8 * 2 + 2) * 8);
     float* l4 = (float*)take(8 * 4);
     WtDesc* wd = c.training ? (WtDesc*)take(pl.L.size() * sizeof(WtDesc)) : nullptr;
-    if (h) h->wt_descs = wd;
+    WbxDesc* xd = (WbxDesc*)take(2 * pl.L.size() * sizeof(WbxDesc));
+    if (h) { h->wt_descs = wd; h->wbx_descs = xd; }
     if (h) { h->stat_part = sp; h->dice_part = dp; h->dice_bc = bc; h->loss4 = l4; }
     return off;
 }
@@ -372,8 +399,49 @@ int launch_thin8(IgemmArgs a, int B, hipStream_t s, const char* layer, double fl
     return 0;
 }
 
+// ---- bf16-pipe implicit GEMM (kernels_bx.hpp): NS = 3 split products in fp32 mode, 1 in bf16 mode ----
+template <int KH, int AMODE, int EPI, int TH, int MB>
+int launch_bx_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+    a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH);
+    dim3 grid(a.tiles, cdiv(a.Mout, MB), B), block(kBlock);
+    char nm[64]; snprintf(nm, sizeof nm, "conv_bx_k<%d,%d,%d,%d,%d,%d,%s>", KH, AMODE, EPI, TH, MB, a.act_bf16 ? 1 : 3, AT_NAME(a.act_bf16));
+    ProfScope ps(s, nm, layer, flops, bytes);
+    if constexpr (AMODE == A_UPF && EPI == EPI_FWD) {
+        if (a.flags & F_DROP) {
+            if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, true, bf16_t><<<grid, block, 0, s>>>(a);
+            else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, true, float><<<grid, block, 0, s>>>(a);
+            HIP_OK(hipGetLastError());
+            *rows = B * a.tiles;
+            return 0;
+        }
+    }
+    if (a.flags & F_DROP) return fail(-3, "conv_bx_k: dropout on the input is only built for the up-conv forward");
+    if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, false, bf16_t><<<grid, block, 0, s>>>(a);
+    else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, false, float><<<grid, block, 0, s>>>(a);
+    HIP_OK(hipGetLastError());
+    *rows = B * a.tiles;
+    return 0;
+}
+template <int KH, int AMODE, int EPI>
+int launch_bx(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+    auto blocks = [&](int th, int mb) { return (long)B * cdiv(a.Ho, th) * cdiv(a.Wo, 32) * cdiv(a.Mout, mb); };
+    if constexpr (AMODE == A_DOWN2) {      // 2x-strided input tile: only the 4-row tile fits the LDS double buffer
+        if (a.Mout % 64 == 0) return launch_bx_geo<KH, AMODE, EPI, 4, 64>(a, B, s, layer, flops, bytes, rows);
+        return launch_bx_geo<KH, AMODE, EPI, 4, 32>(a, B, s, layer, flops, bytes, rows);
+    } else {
+        if (a.Mout % 64 == 0) {
+            if (blocks(8, 64) >= g_bx_min_blocks) return launch_bx_geo<KH, AMODE, EPI, 8, 64>(a, B, s, layer, flops, bytes, rows);
+            return launch_bx_geo<KH, AMODE, EPI, 4, 64>(a, B, s, layer, flops, bytes, rows);
+        }
+        if (blocks(16, 32) >= g_bx_min_blocks) return launch_bx_geo<KH, AMODE, EPI, 16, 32>(a, B, s, layer, flops, bytes, rows);
+        return launch_bx_geo<KH, AMODE, EPI, 8, 32>(a, B, s, layer, flops, bytes, rows);
+    }
+}
+
 template <int KH, int AMODE, int EPI>
 int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+    if (g_mfma_mode && a.wbx && a.Mout % 32 == 0 && a.Cin % 8 == 0 && a.m_off % bx_mb(a.Mout) == 0)
+        return launch_bx<KH, AMODE, EPI>(a, B, s, layer, flops, bytes, rows);
     auto blocks = [&](int th, int mb) { return (long)B * cdiv(a.Ho, th) * cdiv(a.Wo, 32) * cdiv(a.Mout, mb); };
     if constexpr (AMODE == A_NORMAL && KH == 3) {
         // 8 output channels, 3x3: two adjacent pixels share one 16-row MFMA tile (75 % useful instead of 50 %)
@@ -434,6 +502,7 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
         g.Cin = l.cin; g.w = a.w; g.w_ld = l.cout; g.m_off = 0; g.bias = a.bias; g.out = l.z; g.Mout = l.cout;
         g.Ho = l.H; g.Wo = l.W; g.Hi = l.src == SRC_UP ? l.H / 2 : l.H; g.Wi = l.src == SRC_UP ? l.W / 2 : l.W;
         g.part = a.part; g.drop = a.drop; g.act_bf16 = h->cfg.dtype;
+        g.wbx = l.wbx_f; g.wbx_M = l.cout;
         rc = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows)
                              : launch_igemm<3, A_NORMAL, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows);
     } else if (l.src == SRC_INPUT && l.cin == 1 && l.cout == 8 && l.kh == 3) {   // the real first layer: persistent streaming kernel
@@ -517,6 +586,11 @@ int dice_n(int C) { return 5 * C <= 16 ? 16 : (5 * C <= 32 ? 32 : 64); }
 int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, const oct_unet_io* io, hipStream_t s) {
     Plan& pl = h->plan;
     const int nl = (int)pl.L.size();
+    if (g_mfma_mode && h->n_wbx_f) {   // this step's weights, split / rounded into bf16 MFMA operand order (one launch)
+        ProfScope ps(s, "prep_wbx_k", "all", 0, (double)h->wbx_f_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
+        prep_wbx_k<<<std::min<unsigned>((h->wbx_f_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wbx_descs, h->n_wbx_f, h->wbx_f_total);
+        HIP_OK(hipGetLastError());
+    }
     if (!training) {  // (a, b) of every block from the moving statistics: one launch
         ProfScope ps(s, "bn_infer_all_k", "all", 0, (double)pl.n_state * 4 * 3);
         BnInferAll ia{};
@@ -601,7 +675,7 @@ int flush_reduce(oct_unet* h, hipStream_t s) {
 int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const void* dz, int B, hipStream_t s) {
     const Layer& l = h->plan.L[li];
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
-    DwPlan p = dw_plan(l, B);
+    DwPlan p = dw_plan(l, B, g_mfma_mode);
     p.npb = std::min(p.npb, l.dw_rows);
     ConvBwdWArgs a{};
     a.x0 = sd.x0; a.ab0 = sd.ab0; a.C0 = sd.C0; a.x1 = sd.x1; a.ab1 = sd.ab1; a.C1 = sd.C1;
@@ -626,6 +700,14 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
         HIP_OK(hipGetLastError());
     } else if (p.kind == 0) {
         rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by);   // other 1-channel / odd-channel first layers
+    } else if (p.kind == 33) {
+        dim3 grid(p.npb, l.cin / 32, l.cout / 32), block(kBlock);
+        const int bf = a.act_bf16 ? 1 : 0;
+        char nm[64]; snprintf(nm, sizeof nm, "conv_dwbx_k<%d,%s,%d,%s>", l.kh, up ? "true" : "false", bf ? 1 : 3, AT_NAME(bf));
+        ProfScope ps(s, nm, l.name, fl, by);
+        if (up) { if (bf) conv_dwbx_k<2, true, 1, bf16_t><<<grid, block, 0, s>>>(a); else conv_dwbx_k<2, true, 3, float><<<grid, block, 0, s>>>(a); }
+        else { if (bf) conv_dwbx_k<3, false, 1, bf16_t><<<grid, block, 0, s>>>(a); else conv_dwbx_k<3, false, 3, float><<<grid, block, 0, s>>>(a); }
+        HIP_OK(hipGetLastError());
     } else {
         dim3 grid(p.npb, cdiv(l.cin, p.cic), cdiv(l.cout, p.coc)), block(kBlock);
         char nm[64];
@@ -691,6 +773,11 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         prep_wt_k<<<std::min<unsigned>((h->wt_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wt_descs, h->n_wt, h->wt_total);
         HIP_OK(hipGetLastError());
     }
+    if (g_mfma_mode && h->n_wbx_b) {
+        ProfScope ps(s, "prep_wbx_k", "all", 0, (double)h->wbx_b_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
+        prep_wbx_k<<<std::min<unsigned>((h->wbx_b_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wbx_descs + h->n_wbx_f, h->n_wbx_b, h->wbx_b_total);
+        HIP_OK(hipGetLastError());
+    }
     int rc = DISPATCH_C(launch_head_bwd, h->cfg.n_cls, hb, hd.cin, B, s);
     if (rc) return rc;
     int pending_nblk = B * hb.nblk;           // number of stat partial rows waiting for block (li-1)
@@ -722,6 +809,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             g.Hi = l.H; g.Wi = l.W; g.Ho = up ? l.H / 2 : l.H; g.Wo = up ? l.W / 2 : l.W;
             g.part = prod ? h->stat_part : nullptr; g.zin = prod ? prod->z : nullptr; g.bnin = prod ? prod->bn : nullptr;
             g.drop_out = (up && l.drop_in) ? 1 : 0; g.drop = make_drop(h); g.act_bf16 = h->cfg.dtype;
+            g.wbx = l.wbx_b; g.wbx_M = l.cin;
             const double px = (double)B * l.H * l.W, pxg = (double)B * g.Ho * g.Wo;
             const double fl = 2.0 * l.kh * l.kw * Cg * l.cout * px;          // algorithmic flops of the original conv's dX
             const int es = h->cfg.dtype ? 2 : 4;
@@ -862,6 +950,31 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
         h->n_wt = (int)d.size(); h->wt_total = off;
         hipError_t e = hipMemcpy(h->wt_descs, d.data(), d.size() * sizeof(WtDesc), hipMemcpyHostToDevice);
         if (e != hipSuccess) { delete h; return fail(-5, std::string("hipMemcpy(wt_descs): ") + hipGetErrorString(e)); }
+    }
+    {   // split-weight descriptors: forward entries first, then backward-data entries
+        std::vector<WbxDesc> d;
+        const int ns = c->dtype ? 1 : 3;
+        auto items = [](int KH, int Kc, int M, int MB) { return (unsigned)(((Kc + 15) / 16) * ((M + MB - 1) / MB) * KH * KH * MB * 2); };
+        unsigned off = 0;
+        for (auto& l : h->plan.L) {
+            if (!l.wbx_f) continue;
+            WbxDesc w{}; w.src = params + l.w_off; w.dst = l.wbx_f; w.KH = l.kh; w.Kc = l.cin; w.M = l.cout; w.ld = l.cout;
+            w.MB = bx_mb(l.cout); w.NS = ns; w.start = off; w.count = items(w.KH, w.Kc, w.M, w.MB);
+            off += w.count; d.push_back(w);
+        }
+        h->n_wbx_f = (int)d.size(); h->wbx_f_total = off;
+        off = 0;
+        for (auto& l : h->plan.L) {
+            if (!l.wbx_b) continue;
+            WbxDesc w{}; w.src = l.wt; w.dst = l.wbx_b; w.KH = 3; w.Kc = l.cout; w.M = l.cin; w.ld = l.cin;
+            w.MB = bx_mb(bx_bwd_cg(l)); w.NS = ns; w.start = off; w.count = items(3, w.Kc, w.M, w.MB);
+            off += w.count; d.push_back(w);
+        }
+        h->n_wbx_b = (int)d.size() - h->n_wbx_f; h->wbx_b_total = off;
+        if (!d.empty()) {
+            hipError_t e = hipMemcpy(h->wbx_descs, d.data(), d.size() * sizeof(WbxDesc), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { delete h; return fail(-5, std::string("hipMemcpy(wbx_descs): ") + hipGetErrorString(e)); }
+        }
     }
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);
@@ -1049,7 +1162,7 @@ const Opt k_opts[] = {
     {"dw16_blocks", &g_dw16_blocks, 64}, {"igemm_persistent_blocks", &g_igemm_p_blocks, 8},
     {"igemm_min_blocks", &g_igemm_min_blocks, 1}, {"dwpair8_enable", &g_dwpair8, 0},
     {"pair8_geometry", &g_pair_geo, 111}, {"pair8_min_tiles", &g_pair_min_tiles, 1}, {"thin8_min_tiles", &g_thin_min_tiles, 1},
-    {"focal_clip_modulation", &g_focal_clip_mod, 0},
+    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8},
 };
 }  // namespace
 
@@ -1071,6 +1184,9 @@ int oct_set_option(const char* name, int value) {
     if (!strcmp(name, "pair8_min_tiles")) { g_pair_min_tiles = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "thin8_min_tiles")) { g_thin_min_tiles = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "focal_clip_modulation")) { g_focal_clip_mod = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "mfma_mode")) { g_mfma_mode = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "bx_min_blocks")) { g_bx_min_blocks = value < 1 ? 1 : value; return 0; }
+    if (!strcmp(name, "dwbx_blocks")) { g_dwbx_blocks = value < 8 ? 8 : value; return 0; }
     return fail(-1, std::string("unknown option: ") + name);
 }
 
