@@ -670,4 +670,268 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// THIN layers (<= 16 output channels: the full- and half-resolution stages, where the tensors, not the FLOPs, are
+// large) on the bf16 pipe: v_mfma_f32_16x16x32_bf16, M = 16 output channels (8 used by the 8-channel layers),
+// N = 16 consecutive pixels of a row, K = 32 = (32 / CT) taps x CT input channels (CT = 8, 16 or 32 = Cin).
+//   * persistent blocks walk pixel tiles of 8 x 32 (XCD-aware TileWalk); the split weights of the whole layer
+//     (<= 9 MFMA K-groups x NS terms) live in REGISTERS for the lifetime of the block -- no weight traffic at all;
+//   * the input tile goes global -> registers (one tile ahead) -> BN + ReLU -> split -> LDS image
+//     [term][pixel][CT channels] (double buffered, branch-free so that it is scheduled among the MFMAs of the
+//     current tile); a lane's B fragment is ONE ds_read_b128: 8 channels of pixel (x + tap offset) -- lanes 16 kg..16 kg+15
+//     serve K-slice kg = (tap within the group, channel octet), so the tap offset is a per-lane constant;
+//   * BN statistics accumulate in registers across all tiles of the block: ONE partial row per block.
+// Same addressing modes / epilogues / argument block as conv_igemm_p_k.  A.wbx = prep_wbt_k output for this launch's
+// 16-row slice (rows A.m_off .. A.m_off + 15 of the weight matrix).  grid (nblk, 1, 1).
+// ------------------------------------------------------------------------------------------------------------------
+struct WbtDesc {
+    const float* src; bf16_t* dst;
+    int KH, Kc, M, ld, m_off, CT, NS;    // src[(tap * Kc + c) * ld + m]; rows m_off .. m_off + 15
+    unsigned start, count;               // work items: (K-group, row, K-slice)
+};
+
+__global__ __launch_bounds__(kBlock) void prep_wbt_k(const WbtDesc* __restrict__ descs, int nd, unsigned total) {
+    for (unsigned e = blockIdx.x * kBlock + threadIdx.x; e < total; e += gridDim.x * kBlock) {
+        int d = 0;
+        while (d + 1 < nd && e >= descs[d + 1].start) ++d;
+        const WbtDesc D = descs[d];
+        const unsigned r = e - D.start;
+        const int kg = r & 3, m = (r >> 2) & 15, g = r >> 6;
+        const int taps = D.KH * D.KH, tpm = 32 / D.CT;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k32 = kg * 8 + j, tap = g * tpm + k32 / D.CT, c = k32 % D.CT, mg = D.m_off + m;
+            v[j] = (tap < taps && c < D.Kc && mg < D.M) ? D.src[((size_t)tap * D.Kc + c) * D.ld + mg] : 0.f;
+        }
+        bf16_t* base = D.dst + ((size_t)g * D.NS * 16 + m) * 32 + kg * 8;
+        if (D.NS == 3) {
+            uint4 pl[3]; split8<3>(v, pl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(base + (size_t)p * 16 * 32) = pl[p];
+        } else {
+            uint4 pl[1]; split8<1>(v, pl);
+            *reinterpret_cast<uint4*>(base) = pl[0];
+        }
+    }
+}
+__host__ inline int wbt_groups(int KH, int CT) { const int tpm = 32 / CT; return (KH * KH + tpm - 1) / tpm; }
+__host__ inline size_t wbt_bytes(int KH, int CT, int NS) { return (size_t)wbt_groups(KH, CT) * NS * 16 * 32 * 2; }
+
+template <int KH, int AMODE, int EPI, int CT, int NS, typename AT>
+__global__ __launch_bounds__(kBlock, CT == 32 ? 1 : 2) void conv_bt_k(const IgemmArgs A) {
+    constexpr int TH = 8, TW = 32, TAPS = KH * KH, TPM = 32 / CT, NG = (TAPS + TPM - 1) / TPM, OCT = CT / 8;
+    constexpr int NTW = 4, ACC = 4, MB = 16;
+    constexpr int IH = AMODE == A_NORMAL ? TH + KH - 1 : (AMODE == A_UPF ? TH / 2 + 1 : 2 * TH + 1);
+    constexpr int IW = AMODE == A_NORMAL ? TW + KH - 1 : (AMODE == A_UPF ? TW / 2 + 1 : 2 * TW + 1);
+    constexpr int NPIX = IH * IW, PPS = kBlock / OCT, NSLOT = (NPIX + PPS - 1) / PPS, NPIXP = NSLOT * PPS;
+    constexpr int PIXB = CT * 2, PLANE_B = NPIXP * PIXB, IN_B = NS * PLANE_B;
+    constexpr int SWS = OCT == 4 ? 2 : 3;                       // swizzle: octet ^= (pixel >> SWS) & (OCT - 1)
+    __shared__ __attribute__((aligned(256))) char smem[2 * IN_B + (4 * MB + 4 * 2 * MB) * 4];
+    float* const epi = reinterpret_cast<float*>(smem + 2 * IN_B);     // EPI_MASK: producer's BN rows a / b / mean / rstd
+    float* const red = epi + 4 * MB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, kg = lane >> 4;
+
+    // ---- split weights of the whole layer slice -> registers (A operand: row px = output channel, K-slice kg) ----
+    bf16x8 wa[NG][NS];
+    {
+        const char* w = reinterpret_cast<const char*>(A.wbt) + px * 64 + kg * 16;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) wa[g][p] = *reinterpret_cast<const bf16x8*>(w + (g * NS + p) * 16 * 64);
+    }
+    if constexpr (EPI == EPI_MASK) {
+        for (int e = tid; e < 4 * MB; e += kBlock) {
+            const int arr = e / MB, m = e % MB;
+            epi[e] = m < A.Mout ? A.bnin[arr * A.Mout + m] : 0.f;
+        }
+    }
+    const int m4 = 4 * kg;                                       // this lane's output channels m4 .. m4 + 3
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_FWD && m4 < A.Mout) bias = ld4(A.bias + A.m_off + m4);
+
+    // ---- staging set-up: thread serves channel octet o of pixels P_k ----
+    const int o = tid % OCT, c8 = 8 * o;
+    const bool two = (A.flags & F_TWO) && c8 >= A.C0;
+    const int Cs = two ? A.C1 : A.C0, ccx = two ? c8 - A.C0 : c8;
+    const AT* __restrict__ xsrc = (two ? reinterpret_cast<const AT*>(A.x1) : reinterpret_cast<const AT*>(A.x0)) + ccx;
+    const bool aff = (A.flags & F_AFF) != 0;
+    const float lo = aff ? 0.f : -3.0e38f;
+    float fa[8], fb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa[i] = 1.f; fb[i] = 0.f; }
+    if (aff) {
+        const float* ab = two ? A.ab1 : A.ab0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { fa[i] = ab[ccx + i]; fb[i] = ab[Cs + ccx + i]; }
+    }
+    int sly[NSLOT], slx[NSLOT], sdst[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        const int P = tid / OCT + k * PPS;
+        sly[k] = P < NPIX ? P / IW : -1000000; slx[k] = P % IW;                 // pad pixels fall outside every image
+        sdst[k] = P * PIXB + ((o ^ ((P >> SWS) & (OCT - 1))) * 16);
+    }
+    typename Raw4<AT>::type R[NSLOT][2];
+    auto origin = [&](const TileOrg& t, int& iy0, int& ix0) {
+        const int y0 = t.ty * TH, x0 = t.tx * TW;
+        iy0 = AMODE == A_NORMAL ? y0 - (KH - 1) / 2 : (AMODE == A_UPF ? y0 / 2 : 2 * y0 - 1);
+        ix0 = AMODE == A_NORMAL ? x0 - (KH - 1) / 2 : (AMODE == A_UPF ? x0 / 2 : 2 * x0 - 1);
+    };
+    auto load = [&](const TileOrg& t) {                          // unconditional: addresses clamped into the image
+        int iy0, ix0; origin(t, iy0, ix0);
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            int gy = iy0 + sly[k], gx = ix0 + slx[k];
+            gy = gy < 0 ? 0 : (gy >= A.Hi ? A.Hi - 1 : gy); gx = gx < 0 ? 0 : (gx >= A.Wi ? A.Wi - 1 : gx);
+            const AT* p = xsrc + (((size_t)t.b * A.Hi + gy) * A.Wi + gx) * Cs;
+            R[k][0] = ldraw4<AT>(p); R[k][1] = ldraw4<AT>(p + 4);
+        }
+    };
+    auto store = [&](const TileOrg& t, int buf) {
+        int iy0, ix0; origin(t, iy0, ix0);
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            const float4 v0 = widen4(R[k][0]), v1 = widen4(R[k][1]);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const int gy = iy0 + sly[k], gx = ix0 + slx[k];
+            const bool in = gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {      // zero padding is applied AFTER the activation: out-of-image stays 0
+                const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);
+                v[i] = in ? y : 0.f;
+            }
+            uint4 pl[NS];
+            split8<NS>(v, pl);
+            char* d = smem + buf * IN_B + sdst[k];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * PLANE_B) = pl[p];
+        }
+    };
+
+    // ---- per-lane B-fragment geometry: K-slice kg of group g = tap g * TPM + kg / OCT, channel octet kg % OCT ----
+    const int oq = kg % OCT;
+    int tky[NG], tkx[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        int tap = g * TPM + kg / OCT;
+        tap = tap < TAPS ? tap : TAPS - 1;                      // absent taps carry zero weights: any valid address will do
+        tky[g] = tap / KH; tkx[g] = tap % KH;
+    }
+    auto boff = [&](int nt, int g) -> int {                     // byte offset of this lane's fragment in a term's image
+        const int r = 2 * wave + (nt >> 1), x = 16 * (nt & 1) + px;
+        int P;
+        if constexpr (AMODE == A_NORMAL) P = (r + tky[g]) * IW + x + tkx[g];
+        else if constexpr (AMODE == A_UPF) P = ((r + tky[g]) >> 1) * IW + ((x + tkx[g]) >> 1);
+        else P = (2 * r + tky[g]) * IW + 2 * x + tkx[g];
+        return P * PIXB + ((oq ^ ((P >> SWS) & (OCT - 1))) * 16);
+    };
+
+    float s1[ACC] = {0.f, 0.f, 0.f, 0.f}, s2[ACC] = {0.f, 0.f, 0.f, 0.f};
+    TileWalk<TH, TW> walk;
+    walk.init(A.tiles, A.tiles_x, A.total_tiles);
+    TileOrg cur = walk.first(A.tiles);
+    if (walk.tl0 < walk.tlend) {
+        load(cur);
+        store(cur, 0);
+        load(walk.tl0 + walk.step < walk.tlend ? walk.next(cur) : cur);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int tl = walk.tl0; tl < walk.tlend; tl += walk.step, buf ^= 1) {
+        const TileOrg nxt = tl + walk.step < walk.tlend ? walk.next(cur) : cur;
+        const TileOrg nx2 = tl + 2 * walk.step < walk.tlend ? walk.next(nxt) : nxt;
+        const int b = cur.b, y0 = cur.ty * TH, x0 = cur.tx * TW;
+        // producer's z for the epilogue mask: requested now, consumed after the MFMAs
+        typename Raw4<AT>::type zq[EPI == EPI_MASK ? NTW : 1];
+        if constexpr (EPI == EPI_MASK) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                int y = y0 + 2 * wave + (nt >> 1), x = x0 + 16 * (nt & 1) + px;
+                y = y < A.Ho ? y : A.Ho - 1; x = x < A.Wo ? x : A.Wo - 1;
+                const int mm = m4 < A.Mout ? m4 : 0;
+                zq[nt] = ldraw4<AT>(reinterpret_cast<const AT*>(A.zin) + (((size_t)b * A.Ho + y) * A.Wo + x) * A.Mout + mm);
+            }
+        }
+        store(nxt, buf ^ 1);                                    // (a dummy repeat behind the last tile: branch-free body)
+        load(nx2);
+        f32x4 acc[NTW];
+        const char* Ib = smem + buf * IN_B;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const char* q = Ib + boff(nt, g);
+                bf16x8 bv[NS];
+#pragma unroll
+                for (int p = 0; p < NS; ++p) bv[p] = *reinterpret_cast<const bf16x8*>(q + p * PLANE_B);
+                if constexpr (NS == 3) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], bv[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][2], bv[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][1], bv[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], bv[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][1], bv[0], c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], bv[0], c, 0, 0, 0);
+            }
+            acc[nt] = c;
+        }
+        // ---- epilogue of this tile: lane holds channels m4..m4+3 of pixel (row 2 wave + nt/2, x = 16 (nt&1) + px) ----
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int y = y0 + 2 * wave + (nt >> 1), x = x0 + 16 * (nt & 1) + px;
+            const bool valid = y < A.Ho && x < A.Wo && m4 < A.Mout;
+            const size_t pix = ((size_t)b * A.Ho + (y < A.Ho ? y : 0)) * A.Wo + (x < A.Wo ? x : 0);
+            float v[4] = {acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]};
+            if constexpr (EPI == EPI_FWD) {
+                v[0] += bias.x; v[1] += bias.y; v[2] += bias.z; v[3] += bias.w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float u = valid ? v[k] : 0.f; s1[k] += u; s2[k] += u * u; }
+            } else if constexpr (EPI == EPI_MASK) {
+                const float4 zw = widen4(zq[nt]);
+                const float zz[4] = {zw.x, zw.y, zw.z, zw.w};
+                const int ml = m4 < MB ? m4 : 0;
+                const float4 ea = ld4(epi + BN_A * MB + ml), eb = ld4(epi + BN_B * MB + ml);
+                const float4 em = ld4(epi + BN_MEAN * MB + ml), er = ld4(epi + BN_RSTD * MB + ml);
+                const float ka[4] = {ea.x, ea.y, ea.z, ea.w}, kb[4] = {eb.x, eb.y, eb.z, eb.w};
+                const float km[4] = {em.x, em.y, em.z, em.w}, kr[4] = {er.x, er.y, er.z, er.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float yv = fmaf(ka[k], zz[k], kb[k]);
+                    float gv = v[k];
+                    if (A.drop_out) gv *= drop_mul(A.drop, (uint32_t)(pix * A.Mout + (valid ? m4 + k : 0)));
+                    gv = (valid && yv > 0.f) ? gv : 0.f;
+                    const float xh = (zz[k] - km[k]) * kr[k];
+                    v[k] = gv; s1[k] += gv; s2[k] += gv * xh;
+                }
+            }
+            if (valid) sta4<AT>(reinterpret_cast<AT*>(A.out) + pix * A.Mout + m4, make_float4(v[0], v[1], v[2], v[3]));
+        }
+        cur = nxt;
+        __syncthreads();
+    }
+
+    if constexpr (EPI != EPI_RAW) {
+        if (A.part) {
+            // lanes sharing kg hold the same 4 channels for 16 different pixels: reduce over the pixel lanes, then waves
+            subgroup_reduce_rec<ACC, ACC, 8>(s1, lane);
+            subgroup_reduce_rec<ACC, ACC, 8>(s2, lane);
+            const int ci = sub_chan<ACC, 8>(lane), mloc = 4 * kg + ci;
+            red[(wave * 2 + 0) * MB + mloc] = s1[0];
+            red[(wave * 2 + 1) * MB + mloc] = s2[0];
+            __syncthreads();
+            if (tid < 2 * MB) {
+                const int stat = tid / MB, ml = tid % MB;
+                const float s = (red[(0 * 2 + stat) * MB + ml] + red[(1 * 2 + stat) * MB + ml]) +
+                                (red[(2 * 2 + stat) * MB + ml] + red[(3 * 2 + stat) * MB + ml]);
+                if (ml < A.Mout) A.part[(size_t)blockIdx.x * (2 * A.Mout) + (size_t)stat * A.Mout + ml] = s;
+            }
+        }
+    }
+}
+
 }  // namespace oct

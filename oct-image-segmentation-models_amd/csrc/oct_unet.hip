@@ -30,6 +30,7 @@ int g_igemm_min_blocks = 512;     // a layer takes the taller pixel tile only if
 int g_dwpair8 = 1;                // 3x3 layers with 8 output channels: pixel-pair backward-weights kernel (0 = padded 16-column kernel)
 int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
+int g_bt_blocks_per_cu = 0;        // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows: 2, or 1 at 32 input channels)
 int g_dwbx_blocks = 256;           // target grid of a bf16-pipe backward-weights launch (1 block per CU: the kernel needs most of the LDS)
 int g_bx_min_blocks = 256;         // a bf16-pipe launch takes the taller pixel tile only if that still yields this many blocks
 int g_mfma_mode = 1;               // 1: convs with >= 32 output channels run on the bf16 MFMA pipe (kernels_bx.hpp: 6 split products
@@ -86,6 +87,7 @@ struct Layer {
     int dw_rows = 0;       // slabs allocated at creation: a launch never uses more (tuning options may change later)
     float* wt = nullptr;   // backward-data weights: transposed+flipped 3x3, or effective 3x3 of an up-conv (9*cin*cout)
     bf16_t* wbx_f = nullptr; bf16_t* wbx_b = nullptr;   // split weights for the bf16-pipe kernels (forward / backward-data)
+    bf16_t* wbt_f = nullptr; bf16_t* wbt_b = nullptr;   // ... for the thin bf16-pipe kernel (16-row slices; backward: cin / Cg slices)
 };
 
 struct Plan {
@@ -178,6 +180,11 @@ inline bool bx_fwd_ok(const Layer& l) { return l.src != SRC_INPUT && l.has_bn &&
 inline int bx_bwd_cg(const Layer& l) { return l.src == SRC_CONCAT ? l.cin / 2 : l.cin; }
 inline bool bx_bwd_ok(const Layer& l) { return l.src != SRC_INPUT && l.has_bn && l.cout % 8 == 0 && l.cout <= 512 && bx_bwd_cg(l) % 32 == 0; }
 
+// thin bf16-pipe kernel (conv_bt_k): <= 16 output channels per launch, K channels exactly 8, 16 or 32
+inline bool bt_k_ok(int k) { return k == 8 || k == 16 || k == 32; }
+inline bool bt_fwd_ok(const Layer& l) { return l.src != SRC_INPUT && l.has_bn && l.cout <= 16 && l.cout % 4 == 0 && bt_k_ok(l.cin); }
+inline bool bt_bwd_ok(const Layer& l) { const int cg = bx_bwd_cg(l); return l.src != SRC_INPUT && l.has_bn && cg <= 16 && cg % 4 == 0 && bt_k_ok(l.cout); }
+
 // dW plan: which kernel handles a layer, its channel chunking, pixel-tile height and pixel-block count
 struct DwPlan { int kind;  /* 0 = VALU (1-channel input / head), 16, 32, 33 = bf16 pipe (conv_dwbx_k) */ int cic, coc, th, chunks, npb, tiles; };
 DwPlan dw_plan(const Layer& l, int B, int mfma_mode) {
@@ -222,6 +229,7 @@ struct oct_unet {
     float focal_w = 0.f, focal_gamma = 2.f; const float* focal_cw = nullptr;           // focal_dice_loss (0 = plain Dice)
     WtDesc* wt_descs = nullptr; int n_wt = 0; unsigned wt_total = 0;
     WbxDesc* wbx_descs = nullptr; int n_wbx_f = 0, n_wbx_b = 0; unsigned wbx_f_total = 0, wbx_b_total = 0;   // [fwd..., bwd...]
+    WbtDesc* wbt_descs = nullptr; int n_wbt_f = 0, n_wbt_b = 0; unsigned wbt_f_total = 0, wbt_b_total = 0;   // [fwd..., bwd...]
     unsigned long long drop_step = 0; int drop_advance = 0;
     int last_B = 0; int last_training = 0; int have_dice = 0; int dice_final = 0;
     const void* last_x = nullptr; int last_u8 = 0;   // input of the last forward (first layer's dW re-reads it)
@@ -247,7 +255,9 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
         const int ns = c.dtype ? 1 : 3;
         bf16_t* wf = bx_fwd_ok(l) ? (bf16_t*)take(wbx_bytes(l.kh, l.cin, l.cout, bx_mb(l.cout), ns)) : nullptr;
         bf16_t* wb = (c.training && bx_bwd_ok(l)) ? (bf16_t*)take(wbx_bytes(3, l.cout, l.cin, bx_mb(bx_bwd_cg(l)), ns)) : nullptr;
-        if (base) { l.z = z; l.g = g; l.bn = bn; l.wt = wt; l.wbx_f = wf; l.wbx_b = wb; }
+        bf16_t* tf = bt_fwd_ok(l) ? (bf16_t*)take(wbt_bytes(l.kh, l.cin, ns)) : nullptr;
+        bf16_t* tb = (c.training && bt_bwd_ok(l)) ? (bf16_t*)take(wbt_bytes(3, l.cout, ns) * (l.cin / bx_bwd_cg(l))) : nullptr;
+        if (base) { l.z = z; l.g = g; l.bn = bn; l.wt = wt; l.wbx_f = wf; l.wbx_b = wb; l.wbt_f = tf; l.wbt_b = tb; }
         // statistic partial rows: one per pixel tile; the MFMA kernels may use tiles as small as 2 x 32 pixels
         stat_max = std::max(stat_max, B * cdiv(l.H, 2) * cdiv(l.W, kTileX) * 2 * (size_t)std::max(l.cout, l.cin));
         if (c.training) {
@@ -273,7 +283,8 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
     float* l4 = (float*)take(8 * 4);
     WtDesc* wd = c.training ? (WtDesc*)take(pl.L.size() * sizeof(WtDesc)) : nullptr;
     WbxDesc* xd = (WbxDesc*)take(2 * pl.L.size() * sizeof(WbxDesc));
-    if (h) { h->wt_descs = wd; h->wbx_descs = xd; }
+    WbtDesc* td = (WbtDesc*)take(3 * pl.L.size() * sizeof(WbtDesc));
+    if (h) { h->wt_descs = wd; h->wbx_descs = xd; h->wbt_descs = td; }
     if (h) { h->stat_part = sp; h->dice_part = dp; h->dice_bc = bc; h->loss4 = l4; }
     return off;
 }
@@ -438,9 +449,35 @@ int launch_bx(const IgemmArgs& a, int B, hipStream_t s, const char* layer, doubl
     }
 }
 
+// ---- thin bf16-pipe kernel (conv_bt_k): persistent, weights in registers ----
+template <int KH, int AMODE, int EPI>
+int launch_bt(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+    a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, 8); a.total_tiles = B * a.tiles;
+    const int per_cu = a.Cin == 32 ? 1 : 2;
+    const int nblk = std::min(a.total_tiles, g_bt_blocks_per_cu > 0 ? 256 * std::min(g_bt_blocks_per_cu, per_cu) : 256 * per_cu);
+    const int bf = a.act_bf16 ? 1 : 0;
+    char nm[64]; snprintf(nm, sizeof nm, "conv_bt_k<%d,%d,%d,%d,%d,%s>", KH, AMODE, EPI, a.Cin, bf ? 1 : 3, AT_NAME(bf));
+    ProfScope ps(s, nm, layer, flops, bytes);
+#define BT_CASE(CT) case CT: if (bf) conv_bt_k<KH, AMODE, EPI, CT, 1, bf16_t><<<nblk, kBlock, 0, s>>>(a); \
+                             else conv_bt_k<KH, AMODE, EPI, CT, 3, float><<<nblk, kBlock, 0, s>>>(a); break;
+    if constexpr (AMODE == A_DOWN2) {     // the 2x-strided input tile only fits the LDS double buffer at 8 channels
+        switch (a.Cin) { BT_CASE(8) default: return fail(-3, "conv_bt_k: stride-2 gather needs 8 K channels"); }
+    } else {
+        switch (a.Cin) { BT_CASE(8) BT_CASE(16) BT_CASE(32) default: return fail(-3, "conv_bt_k: K channels must be 8, 16 or 32"); }
+    }
+#undef BT_CASE
+    HIP_OK(hipGetLastError());
+    *rows = nblk;
+    return 0;
+}
+
 template <int KH, int AMODE, int EPI>
 int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    if (g_mfma_mode && a.wbx && a.Mout % 32 == 0 && a.Cin % 8 == 0 && a.m_off % bx_mb(a.Mout) == 0)
+    const bool octets_ok = !(a.flags & F_TWO) || a.C0 % 8 == 0;    // staging moves 8-channel octets: one source tensor each
+    if (g_mfma_mode && a.wbt && a.Mout <= 16 && a.Mout % 4 == 0 && bt_k_ok(a.Cin) && !(a.flags & F_DROP) && octets_ok &&
+        (AMODE != A_DOWN2 || a.Cin == 8))
+        return launch_bt<KH, AMODE, EPI>(a, B, s, layer, flops, bytes, rows);
+    if (g_mfma_mode && a.wbx && a.Mout % 32 == 0 && a.Cin % 8 == 0 && a.m_off % bx_mb(a.Mout) == 0 && octets_ok)
         return launch_bx<KH, AMODE, EPI>(a, B, s, layer, flops, bytes, rows);
     auto blocks = [&](int th, int mb) { return (long)B * cdiv(a.Ho, th) * cdiv(a.Wo, 32) * cdiv(a.Mout, mb); };
     if constexpr (AMODE == A_NORMAL && KH == 3) {
@@ -502,7 +539,7 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
         g.Cin = l.cin; g.w = a.w; g.w_ld = l.cout; g.m_off = 0; g.bias = a.bias; g.out = l.z; g.Mout = l.cout;
         g.Ho = l.H; g.Wo = l.W; g.Hi = l.src == SRC_UP ? l.H / 2 : l.H; g.Wi = l.src == SRC_UP ? l.W / 2 : l.W;
         g.part = a.part; g.drop = a.drop; g.act_bf16 = h->cfg.dtype;
-        g.wbx = l.wbx_f; g.wbx_M = l.cout;
+        g.wbx = l.wbx_f; g.wbx_M = l.cout; g.wbt = l.wbt_f;
         rc = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows)
                              : launch_igemm<3, A_NORMAL, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows);
     } else if (l.src == SRC_INPUT && l.cin == 1 && l.cout == 8 && l.kh == 3) {   // the real first layer: persistent streaming kernel
@@ -589,6 +626,11 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
     if (g_mfma_mode && h->n_wbx_f) {   // this step's weights, split / rounded into bf16 MFMA operand order (one launch)
         ProfScope ps(s, "prep_wbx_k", "all", 0, (double)h->wbx_f_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
         prep_wbx_k<<<std::min<unsigned>((h->wbx_f_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wbx_descs, h->n_wbx_f, h->wbx_f_total);
+        HIP_OK(hipGetLastError());
+    }
+    if (g_mfma_mode && h->n_wbt_f) {
+        ProfScope ps(s, "prep_wbt_k", "all", 0, (double)h->wbt_f_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
+        prep_wbt_k<<<std::min<unsigned>((h->wbt_f_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wbt_descs, h->n_wbt_f, h->wbt_f_total);
         HIP_OK(hipGetLastError());
     }
     if (!training) {  // (a, b) of every block from the moving statistics: one launch
@@ -778,6 +820,11 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         prep_wbx_k<<<std::min<unsigned>((h->wbx_b_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wbx_descs + h->n_wbx_f, h->n_wbx_b, h->wbx_b_total);
         HIP_OK(hipGetLastError());
     }
+    if (g_mfma_mode && h->n_wbt_b) {
+        ProfScope ps(s, "prep_wbt_k", "all", 0, (double)h->wbt_b_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
+        prep_wbt_k<<<std::min<unsigned>((h->wbt_b_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wbt_descs + h->n_wbt_f, h->n_wbt_b, h->wbt_b_total);
+        HIP_OK(hipGetLastError());
+    }
     int rc = DISPATCH_C(launch_head_bwd, h->cfg.n_cls, hb, hd.cin, B, s);
     if (rc) return rc;
     int pending_nblk = B * hb.nblk;           // number of stat partial rows waiting for block (li-1)
@@ -810,6 +857,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             g.part = prod ? h->stat_part : nullptr; g.zin = prod ? prod->z : nullptr; g.bnin = prod ? prod->bn : nullptr;
             g.drop_out = (up && l.drop_in) ? 1 : 0; g.drop = make_drop(h); g.act_bf16 = h->cfg.dtype;
             g.wbx = l.wbx_b; g.wbx_M = l.cin;
+            g.wbt = l.wbt_b ? l.wbt_b + (size_t)(ci_off / Cg) * (wbt_bytes(3, l.cout, h->cfg.dtype ? 1 : 3) / 2) : nullptr;
             const double px = (double)B * l.H * l.W, pxg = (double)B * g.Ho * g.Wo;
             const double fl = 2.0 * l.kh * l.kw * Cg * l.cout * px;          // algorithmic flops of the original conv's dX
             const int es = h->cfg.dtype ? 2 : 4;
@@ -974,6 +1022,34 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
         if (!d.empty()) {
             hipError_t e = hipMemcpy(h->wbx_descs, d.data(), d.size() * sizeof(WbxDesc), hipMemcpyHostToDevice);
             if (e != hipSuccess) { delete h; return fail(-5, std::string("hipMemcpy(wbx_descs): ") + hipGetErrorString(e)); }
+        }
+    }
+    {   // thin-kernel weight slices: forward entries first, then backward-data entries (one per 16-row slice)
+        std::vector<WbtDesc> d;
+        const int ns = c->dtype ? 1 : 3;
+        unsigned off = 0;
+        for (auto& l : h->plan.L) {
+            if (!l.wbt_f) continue;
+            WbtDesc w{}; w.src = params + l.w_off; w.dst = l.wbt_f; w.KH = l.kh; w.Kc = l.cin; w.M = l.cout; w.ld = l.cout;
+            w.m_off = 0; w.CT = l.cin; w.NS = ns; w.start = off; w.count = (unsigned)wbt_groups(l.kh, l.cin) * 64;
+            off += w.count; d.push_back(w);
+        }
+        h->n_wbt_f = (int)d.size(); h->wbt_f_total = off;
+        off = 0;
+        for (auto& l : h->plan.L) {
+            if (!l.wbt_b) continue;
+            const int cg = bx_bwd_cg(l);
+            for (int sl = 0; sl < l.cin / cg; ++sl) {
+                WbtDesc w{}; w.src = l.wt; w.dst = l.wbt_b + (size_t)sl * (wbt_bytes(3, l.cout, ns) / 2); w.KH = 3; w.Kc = l.cout;
+                w.M = l.cin; w.ld = l.cin; w.m_off = sl * cg; w.CT = l.cout; w.NS = ns; w.start = off;
+                w.count = (unsigned)wbt_groups(3, l.cout) * 64;
+                off += w.count; d.push_back(w);
+            }
+        }
+        h->n_wbt_b = (int)d.size() - h->n_wbt_f; h->wbt_b_total = off;
+        if (!d.empty()) {
+            hipError_t e = hipMemcpy(h->wbt_descs, d.data(), d.size() * sizeof(WbtDesc), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { delete h; return fail(-5, std::string("hipMemcpy(wbt_descs): ") + hipGetErrorString(e)); }
         }
     }
     float lut[256];
@@ -1162,7 +1238,7 @@ const Opt k_opts[] = {
     {"dw16_blocks", &g_dw16_blocks, 64}, {"igemm_persistent_blocks", &g_igemm_p_blocks, 8},
     {"igemm_min_blocks", &g_igemm_min_blocks, 1}, {"dwpair8_enable", &g_dwpair8, 0},
     {"pair8_geometry", &g_pair_geo, 111}, {"pair8_min_tiles", &g_pair_min_tiles, 1}, {"thin8_min_tiles", &g_thin_min_tiles, 1},
-    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8},
+    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0},
 };
 }  // namespace
 
@@ -1187,6 +1263,7 @@ int oct_set_option(const char* name, int value) {
     if (!strcmp(name, "mfma_mode")) { g_mfma_mode = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bx_min_blocks")) { g_bx_min_blocks = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "dwbx_blocks")) { g_dwbx_blocks = value < 8 ? 8 : value; return 0; }
+    if (!strcmp(name, "bt_blocks_per_cu")) { g_bt_blocks_per_cu = value < 0 ? 0 : value; return 0; }
     return fail(-1, std::string("unknown option: ") + name);
 }
 
