@@ -719,7 +719,7 @@ __host__ inline int wbt_groups(int KH, int CT) { const int tpm = 32 / CT; return
 __host__ inline size_t wbt_bytes(int KH, int CT, int NS) { return (size_t)wbt_groups(KH, CT) * NS * 16 * 32 * 2; }
 
 template <int KH, int AMODE, int EPI, int CT, int NS, typename AT>
-__global__ __launch_bounds__(kBlock, CT == 32 ? 1 : 2) void conv_bt_k(const IgemmArgs A) {
+__global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void conv_bt_k(const IgemmArgs A) {
     constexpr int TH = 8, TW = 32, TAPS = KH * KH, TPM = 32 / CT, NG = (TAPS + TPM - 1) / TPM, OCT = CT / 8;
     constexpr int NTW = 4, ACC = 4, MB = 16;
     constexpr int IH = AMODE == A_NORMAL ? TH + KH - 1 : (AMODE == A_UPF ? TH / 2 + 1 : 2 * TH + 1);
@@ -775,23 +775,37 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : 2) void conv_bt_k(const Igem
         sly[k] = P < NPIX ? P / IW : -1000000; slx[k] = P % IW;                 // pad pixels fall outside every image
         sdst[k] = P * PIXB + ((o ^ ((P >> SWS) & (OCT - 1))) * 16);
     }
-    typename Raw4<AT>::type R[NSLOT][2];
+    struct RegSet { typename Raw4<AT>::type v[NSLOT][2]; };
     auto origin = [&](const TileOrg& t, int& iy0, int& ix0) {
         const int y0 = t.ty * TH, x0 = t.tx * TW;
         iy0 = AMODE == A_NORMAL ? y0 - (KH - 1) / 2 : (AMODE == A_UPF ? y0 / 2 : 2 * y0 - 1);
         ix0 = AMODE == A_NORMAL ? x0 - (KH - 1) / 2 : (AMODE == A_UPF ? x0 / 2 : 2 * x0 - 1);
     };
-    auto load = [&](const TileOrg& t) {                          // unconditional: addresses clamped into the image
-        int iy0, ix0; origin(t, iy0, ix0);
+    int soff[NSLOT];                                             // element offset of slot k relative to the tile origin (interior tiles)
 #pragma unroll
-        for (int k = 0; k < NSLOT; ++k) {
-            int gy = iy0 + sly[k], gx = ix0 + slx[k];
-            gy = gy < 0 ? 0 : (gy >= A.Hi ? A.Hi - 1 : gy); gx = gx < 0 ? 0 : (gx >= A.Wi ? A.Wi - 1 : gx);
-            const AT* p = xsrc + (((size_t)t.b * A.Hi + gy) * A.Wi + gx) * Cs;
-            R[k][0] = ldraw4<AT>(p); R[k][1] = ldraw4<AT>(p + 4);
+    for (int k = 0; k < NSLOT; ++k) {
+        const int P = tid / OCT + k * PPS, Pc = P < NPIX ? P : 0;
+        soff[k] = ((Pc / IW) * A.Wi + Pc % IW) * Cs;
+    }
+    auto load = [&](const TileOrg& t, RegSet& RS) {              // unconditional loads: no exec-mask branches
+        auto& R = RS.v;
+        int iy0, ix0; origin(t, iy0, ix0);
+        if (iy0 >= 0 && ix0 >= 0 && iy0 + IH <= A.Hi && ix0 + IW <= A.Wi) {       // interior: wave-uniform base + constant
+            const AT* tb = xsrc + (((size_t)t.b * A.Hi + iy0) * A.Wi + ix0) * Cs;
+#pragma unroll
+            for (int k = 0; k < NSLOT; ++k) { R[k][0] = ldraw4<AT>(tb + soff[k]); R[k][1] = ldraw4<AT>(tb + soff[k] + 4); }
+        } else {                                                 // border: addresses clamped into the image
+#pragma unroll
+            for (int k = 0; k < NSLOT; ++k) {
+                int gy = iy0 + sly[k], gx = ix0 + slx[k];
+                gy = gy < 0 ? 0 : (gy >= A.Hi ? A.Hi - 1 : gy); gx = gx < 0 ? 0 : (gx >= A.Wi ? A.Wi - 1 : gx);
+                const AT* p = xsrc + (((size_t)t.b * A.Hi + gy) * A.Wi + gx) * Cs;
+                R[k][0] = ldraw4<AT>(p); R[k][1] = ldraw4<AT>(p + 4);
+            }
         }
     };
-    auto store = [&](const TileOrg& t, int buf) {
+    auto store = [&](const TileOrg& t, int buf, const RegSet& RS) {
+        auto& R = RS.v;
         int iy0, ix0; origin(t, iy0, ix0);
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) {
@@ -821,29 +835,42 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : 2) void conv_bt_k(const Igem
         tap = tap < TAPS ? tap : TAPS - 1;                      // absent taps carry zero weights: any valid address will do
         tky[g] = tap / KH; tkx[g] = tap % KH;
     }
-    auto boff = [&](int nt, int g) -> int {                     // byte offset of this lane's fragment in a term's image
-        const int r = 2 * wave + (nt >> 1), x = 16 * (nt & 1) + px;
-        int P;
-        if constexpr (AMODE == A_NORMAL) P = (r + tky[g]) * IW + x + tkx[g];
-        else if constexpr (AMODE == A_UPF) P = ((r + tky[g]) >> 1) * IW + ((x + tkx[g]) >> 1);
-        else P = (2 * r + tky[g]) * IW + 2 * x + tkx[g];
-        return P * PIXB + ((oq ^ ((P >> SWS) & (OCT - 1))) * 16);
-    };
+    int bofs[NTW][NG];                                          // byte offset of this lane's fragment in a term's image
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int r = 2 * wave + (nt >> 1), x = 16 * (nt & 1) + px;
+            int P;
+            if constexpr (AMODE == A_NORMAL) P = (r + tky[g]) * IW + x + tkx[g];
+            else if constexpr (AMODE == A_UPF) P = ((r + tky[g]) >> 1) * IW + ((x + tkx[g]) >> 1);
+            else P = (2 * r + tky[g]) * IW + 2 * x + tkx[g];
+            bofs[nt][g] = P * PIXB + ((oq ^ ((P >> SWS) & (OCT - 1))) * 16);
+        }
 
     float s1[ACC] = {0.f, 0.f, 0.f, 0.f}, s2[ACC] = {0.f, 0.f, 0.f, 0.f};
     TileWalk<TH, TW> walk;
     walk.init(A.tiles, A.tiles_x, A.total_tiles);
+    // Global loads run one tile ahead in registers.  (Two tiles ahead -- DEEP -- was measured: the second register set
+    // costs a resident block per CU at 8 channels and pushes the 16-channel mask epilogue past its register budget:
+    // 1.33 -> 1.49 ms over the thin layers of a step.)
+    constexpr bool DEEP = false;
+    RegSet R0, R1;
     TileOrg cur = walk.first(A.tiles);
     if (walk.tl0 < walk.tlend) {
-        load(cur);
-        store(cur, 0);
-        load(walk.tl0 + walk.step < walk.tlend ? walk.next(cur) : cur);
+        const TileOrg n1 = walk.tl0 + walk.step < walk.tlend ? walk.next(cur) : cur;
+        const TileOrg n2 = walk.tl0 + 2 * walk.step < walk.tlend ? walk.next(n1) : n1;
+        load(cur, R0);
+        store(cur, 0, R0);
+        load(n1, R0);
+        if constexpr (DEEP) load(n2, R1);
     }
     __syncthreads();
     int buf = 0;
     for (int tl = walk.tl0; tl < walk.tlend; tl += walk.step, buf ^= 1) {
         const TileOrg nxt = tl + walk.step < walk.tlend ? walk.next(cur) : cur;
         const TileOrg nx2 = tl + 2 * walk.step < walk.tlend ? walk.next(nxt) : nxt;
+        const TileOrg nx3 = tl + 3 * walk.step < walk.tlend ? walk.next(nx2) : nx2;
         const int b = cur.b, y0 = cur.ty * TH, x0 = cur.tx * TW;
         // producer's z for the epilogue mask: requested now, consumed after the MFMAs
         typename Raw4<AT>::type zq[EPI == EPI_MASK ? NTW : 1];
@@ -856,29 +883,49 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : 2) void conv_bt_k(const Igem
                 zq[nt] = ldraw4<AT>(reinterpret_cast<const AT*>(A.zin) + (((size_t)b * A.Ho + y) * A.Wo + x) * A.Mout + mm);
             }
         }
-        store(nxt, buf ^ 1);                                    // (a dummy repeat behind the last tile: branch-free body)
-        load(nx2);
+        store(nxt, buf ^ 1, R0);                                // (a dummy repeat behind the last tile: branch-free body)
+        if constexpr (DEEP) { R0 = R1; load(nx3, R1); }
+        else load(nx2, R0);
         f32x4 acc[NTW];
         const char* Ib = smem + buf * IN_B;
+        {   // flat sequence of (pixel group, K group) steps; the B fragments of step s+2 are requested before the MFMAs of
+            // step s issue (ring of 3 fragment sets): an LDS round trip is longer than the 6 MFMAs of one step
+            constexpr int STEPS = NTW * NG, DEPTH = 3;
+            bf16x8 bv[DEPTH][NS];
+            auto fetch = [&](int st, bf16x8 (&f)[NS]) {
+                const char* q = Ib + bofs[st / NG][st % NG];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
+                for (int p = 0; p < NS; ++p) f[p] = *reinterpret_cast<const bf16x8*>(q + p * PLANE_B);
+            };
+            fetch(0, bv[0]);
+            if (STEPS > 1) fetch(1, bv[1]);
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const char* q = Ib + boff(nt, g);
-                bf16x8 bv[NS];
-#pragma unroll
-                for (int p = 0; p < NS; ++p) bv[p] = *reinterpret_cast<const bf16x8*>(q + p * PLANE_B);
+            for (int st = 0; st < STEPS; ++st) {
+                if (st + 2 < STEPS) fetch(st + 2, bv[(st + 2) % DEPTH]);
+                const int g = st % NG;
+                const bf16x8 (&b)[NS] = bv[st % DEPTH];
                 if constexpr (NS == 3) {
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], bv[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][2], bv[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][1], bv[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], bv[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][1], bv[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], b[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][2], b[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][1], b[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], b[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][1], b[0], c, 0, 0, 0);
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], bv[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], b[0], c, 0, 0, 0);
+                if (g == NG - 1) { acc[st / NG] = c; c = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
-            acc[nt] = c;
+            // pin the schedule of this basic block (hipcc otherwise sinks every LDS read next to its use): fragments two
+            // steps ahead, then the step's MFMAs with a share of the next tile's conversion VALU in their shadow
+            constexpr int NPROD = NS == 3 ? 6 : 1, VPS = NS == 3 ? 16 : 8;
+            __builtin_amdgcn_sched_group_barrier(0x100, STEPS > 1 ? 2 * NS : NS, 0);
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                if (st + 2 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPS, 0);
+                if (st % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, NS, 0);
+            }
         }
         // ---- epilogue of this tile: lane holds channels m4..m4+3 of pixel (row 2 wave + nt/2, x = 16 (nt&1) + px) ----
 #pragma unroll

@@ -30,7 +30,7 @@ int g_igemm_min_blocks = 512;     // a layer takes the taller pixel tile only if
 int g_dwpair8 = 1;                // 3x3 layers with 8 output channels: pixel-pair backward-weights kernel (0 = padded 16-column kernel)
 int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
-int g_bt_blocks_per_cu = 0;        // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows: 2, or 1 at 32 input channels)
+int g_bt_blocks_per_cu = 0;        // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows: 3 / 2 / 1 at 8 / 16 / 32 input channels)
 int g_dwbx_blocks = 256;           // target grid of a bf16-pipe backward-weights launch (1 block per CU: the kernel needs most of the LDS)
 int g_bx_min_blocks = 256;         // a bf16-pipe launch takes the taller pixel tile only if that still yields this many blocks
 int g_mfma_mode = 1;               // 1: convs with >= 32 output channels run on the bf16 MFMA pipe (kernels_bx.hpp: 6 split products
@@ -453,7 +453,7 @@ int launch_bx(const IgemmArgs& a, int B, hipStream_t s, const char* layer, doubl
 template <int KH, int AMODE, int EPI>
 int launch_bt(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
     a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, 8); a.total_tiles = B * a.tiles;
-    const int per_cu = a.Cin == 32 ? 1 : 2;
+    const int per_cu = a.Cin == 32 ? 1 : (a.Cin == 16 ? 2 : 3);     // what the LDS images and registers of the instantiation allow
     const int nblk = std::min(a.total_tiles, g_bt_blocks_per_cu > 0 ? 256 * std::min(g_bt_blocks_per_cu, per_cu) : 256 * per_cu);
     const int bf = a.act_bf16 ? 1 : 0;
     char nm[64]; snprintf(nm, sizeof nm, "conv_bt_k<%d,%d,%d,%d,%d,%s>", KH, AMODE, EPI, a.Cin, bf ? 1 : 3, AT_NAME(bf));

@@ -235,11 +235,20 @@ class UNetEngine:
 
     # ---- arithmetic mode of the convolution kernels (reported by bench.py) --------------------------
     def mfma_products(self) -> int:
-        """0: the convolutions run on the f32 MFMA pipe.  n > 0: on the bf16 pipe, n bf16 products per product."""
-        return 0
+        """0: the convolutions run on the f32 MFMA pipe.  n > 0: on the bf16 pipe, n bf16 products per product
+        (6 = exact three-term split of both fp32 operands, csrc/kernels_bx.hpp; 1 = bf16 operands, cfg.dtype 1)."""
+        if not _hip.get_option("mfma_mode"):
+            return 0
+        return 1 if self.cfg.dtype == 1 else 6
 
     def mfma_mode_name(self) -> str:
-        return "f32 MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32), f32 accumulate"
+        n = self.mfma_products()
+        if n == 0:
+            return "f32 MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32), f32 accumulate"
+        if n == 1:
+            return "bf16 MFMA (v_mfma_f32_32x32x16_bf16 / 16x16x32), bf16 operands, f32 accumulate"
+        return ("fp32 via exact 3-term bf16 split: 6 bf16 MFMAs (v_mfma_f32_32x32x16_bf16 / 16x16x32) per fp32 product, "
+                "f32 accumulate (first layer / head: f32 VALU)")
 
     # ---- per-launch profiler ---------------------------------------------------------------------
     def profile_begin(self):

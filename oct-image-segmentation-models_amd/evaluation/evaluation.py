@@ -24,7 +24,9 @@ from ..common import (EVALUATION_METRIC_AVERAGE_SURFACE_DISTANCE, EVALUATION_MET
 from ..common import utils as common_utils
 from ..min_path_processing import graph_search, utils
 from ..models import get_model_class
+from ..min_path_processing.pool import SegmentPool
 from .evaluation_parameters import EvaluationParameters
+from .pipeline import BatchedPredictor
 
 EVALUATION_RESULTS_FILENAME = "evaluation_results.hdf5"
 GS_EVALUATION_RESULTS_FILENAME = "gs_evaluation_results.hdf5"
@@ -101,15 +103,30 @@ def evaluate_model(eval_params: EvaluationParameters) -> List[EvaluationOutput]:
 
     lo, hi = parallel.shard_range(n_images, rank, world)
     eval_outputs: List[EvaluationOutput] = []
-    graph_structure = None
-    bs = max(1, int(eval_params.batch_size))
-    for b0 in range(lo, hi, bs):
-        b1 = min(b0 + bs, hi)
-        start_predict_time = time.time()
-        # raw uint8 images go to the device; the /255 preprocessing is fused into the first conv's load
-        label_maps, dev_maps = eval_params.loaded_model.predict_labels(eval_images[b0:b1], batch_size=bs, want_maps=True,
-                                                                       bg_ilm=True, bg_csi=False)
-        predict_time = (time.time() - start_predict_time) / (b1 - b0)
+    bs = max(1, min(int(eval_params.batch_size), max(hi - lo, 1)))
+    # BASELINE configs[4] path (evaluation/pipeline.py): the worker pool for the host min-path post-process is started
+    # BEFORE the first GPU call of this process; the forward is a hipGraph replay at the configured batch with pinned,
+    # double-buffered uint8 upload / download; a batch's graph search runs on the pool, not image by image on one core
+    pool = None
+    if eval_params.graph_search and hi > lo:
+        pool = SegmentPool(eval_images.shape[1:3], eval_params.gsgrad, getattr(eval_params, "gs_workers", None))
+    batches = ()
+    if hi > lo and eval_images.dtype == np.uint8:
+        engine = eval_params.loaded_model._ensure_engine(bs, False)
+        batches = BatchedPredictor(engine, bs, want_maps=True, bg_ilm=True, bg_csi=False).run(eval_images[lo:hi])
+    elif hi > lo:      # non-uint8 datasets: x / 255 on the host (Model.predict_labels), same outputs, no overlap
+        def _plain():
+            for r0 in range(0, hi - lo, bs):
+                r1 = min(r0 + bs, hi - lo)
+                lm, dm = eval_params.loaded_model.predict_labels(eval_images[lo + r0:lo + r1], batch_size=bs, want_maps=True,
+                                                                 bg_ilm=True, bg_csi=False)
+                yield r0, r1, lm, dm
+        batches = _plain()
+    t_prev = time.time()
+    for rb0, rb1, label_maps, dev_maps in batches:
+        b0, b1 = lo + rb0, lo + rb1
+        predict_time = (time.time() - t_prev) / (b1 - b0)
+        gs_batch = pool.segment(dev_maps, eval_segments[b0:b1]) if pool is not None else None
         for ind in range(b0, b1):
             eval_image, eval_image_name = eval_images[ind], eval_image_names[ind]
             eval_seg, eval_image_output_dir = eval_segments[ind], eval_image_output_dirs[ind]
@@ -130,11 +147,8 @@ def evaluate_model(eval_params: EvaluationParameters) -> List[EvaluationOutput]:
             gs_pred_segs = errors = mean_abs_err = mean_err = abs_err_sd = err_sd = None
             if eval_params.graph_search:
                 eval_image_t = np.transpose(eval_image, axes=[1, 0, 2])
-                boundary_maps_t = np.transpose(boundary_maps, axes=[0, 2, 1])
-                if graph_structure is None:   # implicit grid: built once, not per image
-                    graph_structure = graph_search.create_graph_structure(eval_image_t.shape, eval_params.gsgrad)
                 start_graph_time = time.time()
-                gs_pred_segs, errors, _ = graph_search.segment_maps(boundary_maps_t, eval_seg, graph_structure)
+                gs_pred_segs, errors = gs_batch[ind - b0]          # == graph_search.segment_maps(boundary_maps_t, eval_seg, grid)
                 reconstructed_maps = common_utils.create_area_mask(eval_image_t.shape, gs_pred_segs)
                 reconstructed_maps = np.expand_dims(common_utils.to_categorical(reconstructed_maps, num_classes), axis=0)
                 [gs_eval_label, reconstructed_maps] = common_utils.perform_argmax(reconstructed_maps)
@@ -152,6 +166,9 @@ def evaluate_model(eval_params: EvaluationParameters) -> List[EvaluationOutput]:
                 categorical_pred=categorical_pred, boundary_maps=boundary_maps, gs_pred_segs=gs_pred_segs, errors=errors,
                 mean_abs_err=mean_abs_err, mean_err=mean_err, abs_err_sd=abs_err_sd, err_sd=err_sd,
                 dice_classes=dice_classes, dice_macro=dice_macro, dice_micro=dice_micro))
+        t_prev = time.time()
+    if pool is not None:
+        pool.close()
     parallel.barrier()
     if rank == 0:
         _calc_overall_dataset_errors(eval_params, eval_image_names)

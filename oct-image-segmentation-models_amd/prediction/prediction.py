@@ -13,7 +13,9 @@ import numpy as np
 
 from .. import parallel
 from ..common import h5io, utils
-from ..min_path_processing import graph_search
+from ..evaluation.pipeline import BatchedPredictor
+from ..min_path_processing import graph_search  # noqa: F401  (re-exported: callers build graph structures through it)
+from ..min_path_processing.pool import SegmentPool
 from ..models import get_model_class
 from .prediction_parameters import PredictionParams
 
@@ -48,14 +50,28 @@ def predict(predict_params: PredictionParams) -> List[PredictionOutput]:
 
     outputs: List[PredictionOutput] = []
     lo, hi = parallel.shard_range(len(images), rank, world)
-    bs = max(1, int(predict_params.batch_size))
-    graph_structure = None
-    for b0 in range(lo, hi, bs):
-        b1 = min(b0 + bs, hi)
-        t0 = time.time()
-        label_maps, dev_maps = predict_params.loaded_model.predict_labels(images[b0:b1], batch_size=bs, want_maps=True,
-                                                                          bg_ilm=True, bg_csi=False)
+    bs = max(1, min(int(predict_params.batch_size), max(hi - lo, 1)))
+    # same device pipeline as evaluate_model (evaluation/pipeline.py): worker pool first, then the hipGraph replay with
+    # pinned double-buffered uint8 transfers; non-uint8 images take the host x / 255 path of Model.predict_labels
+    pool = None
+    if predict_params.graph_search and hi > lo:
+        pool = SegmentPool(images.shape[1:3], 1, getattr(predict_params, "gs_workers", None))
+    if hi > lo and images.dtype == np.uint8:
+        engine = predict_params.loaded_model._ensure_engine(bs, False)
+        batches = BatchedPredictor(engine, bs, want_maps=True, bg_ilm=True, bg_csi=False).run(images[lo:hi])
+    else:
+        def _plain():
+            for r0 in range(0, hi - lo, bs):
+                r1 = min(r0 + bs, hi - lo)
+                lm, dm = predict_params.loaded_model.predict_labels(images[lo + r0:lo + r1], batch_size=bs, want_maps=True,
+                                                                    bg_ilm=True, bg_csi=False)
+                yield r0, r1, lm, dm
+        batches = _plain()
+    t0 = time.time()
+    for rb0, rb1, label_maps, dev_maps in batches:
+        b0, b1 = lo + rb0, lo + rb1
         predict_time = (time.time() - t0) / (b1 - b0)
+        gs_batch = pool.segment(dev_maps, None) if pool is not None else None
         for i in range(b0, b1):
             predict_image, image_name, image_output_dir = images[i], dataset.image_names[i], Path(dataset.image_output_dirs[i])
             os.makedirs(image_output_dir, exist_ok=True)
@@ -73,11 +89,8 @@ def predict(predict_params: PredictionParams) -> List[PredictionOutput]:
             gs_pred_segs = None
             if predict_params.graph_search:
                 predict_image_t = np.transpose(predict_image, axes=[1, 0, 2])
-                boundary_maps_t = np.transpose(boundary_maps, axes=[0, 2, 1])
-                if graph_structure is None:
-                    graph_structure = graph_search.create_graph_structure(predict_image_t.shape)
                 start_graph_time = time.time()
-                gs_pred_segs, _, _ = graph_search.segment_maps(boundary_maps_t, None, graph_structure)
+                gs_pred_segs = gs_batch[i - b0][0]               # == graph_search.segment_maps(boundary_maps_t, None, grid)
                 reconstructed_maps = utils.create_area_mask(predict_image_t.shape, gs_pred_segs)
                 reconstructed_maps = np.expand_dims(utils.to_categorical(reconstructed_maps, num_classes), axis=0)
                 [gs_prediction_label, reconstructed_maps] = utils.perform_argmax(reconstructed_maps)
@@ -88,6 +101,9 @@ def predict(predict_params: PredictionParams) -> List[PredictionOutput]:
             outputs.append(PredictionOutput(image=predict_image, image_name=image_name, image_output_dir=image_output_dir,
                                             predicted_labels=predicted_labels, categorical_pred=categorical_pred,
                                             boundary_maps=boundary_maps, gs_pred_segs=gs_pred_segs))
+        t0 = time.time()
+    if pool is not None:
+        pool.close()
     parallel.barrier()
     return outputs
 

@@ -517,6 +517,60 @@ def bf16_ulp(a):
     return 2.0 ** (np.floor(np.log2(np.maximum(np.abs(a), 1e-30))) - 7)
 
 
+# ---- which arithmetic a layer runs in bf16 mode (dtype=1): mirror of the host rules in csrc/oct_unet.hip (bx_fwd_ok /
+# bt_fwd_ok / bx_bwd_ok / bt_bwd_ok / dw_plan).  On the bf16 MFMA pipe (mfma_mode 1, the default) BOTH operands of a
+# product are bf16: the activation is rounded once more after BN + ReLU (dz operands are stored bf16 already: exact)
+# and the weights are rounded per step; accumulation stays fp32.  Layers outside those rules (first layer, head,
+# channel counts that are not multiples of 8, mfma_mode 0) multiply the stored bf16 values with fp32 weights. ----
+def _bt_k(k):
+    return k in (8, 16, 32)
+
+
+def bf16_fwd_operands(plan, li, cfg, mfma_mode):
+    sp = plan[li]
+    if not mfma_mode or sp.src == "input" or not sp.has_bn:
+        return False
+    drop = sp.name == "dec0.up" and cfg.dropout_rate > 0
+    two_ok = sp.src != "concat" or plan[li - 1].cout % 8 == 0
+    thin = sp.cout <= 16 and sp.cout % 4 == 0 and _bt_k(sp.cin) and not drop and two_ok
+    wide = sp.cout % 32 == 0 and sp.cin % 8 == 0 and sp.cin <= 512 and two_ok
+    return thin or wide
+
+
+def bf16_dx_weights(plan, li, mfma_mode):
+    sp = plan[li]
+    if not mfma_mode or sp.src == "input" or not sp.has_bn:
+        return False
+    cg = sp.cin // 2 if sp.src == "concat" else sp.cin
+    wide = cg % 32 == 0 and sp.cout % 8 == 0 and sp.cout <= 512
+    thin = cg <= 16 and cg % 4 == 0 and (sp.cout == 8 if sp.src == "up" else _bt_k(sp.cout))
+    return wide or thin
+
+
+def bf16_dw_operands(plan, li, mfma_mode):
+    sp = plan[li]
+    return bool(mfma_mode) and sp.src != "input" and sp.kh != 1 and sp.cin % 32 == 0 and sp.cout % 32 == 0
+
+
+def upconv_dx_effective(dz, kernel, round_w):
+    """Backward-data of UpSampling2D(2) -> Conv2D(2x2, same) as the engine forms it (prep_wt_k mode 1 + A_DOWN2): a 3x3
+    stride-2 gather over dz with effective weights Weff[a][b] = sum of the 2x2 taps that reach that offset; the
+    EFFECTIVE weights are what the bf16 pipe rounds."""
+    B, H2, W2, Co = dz.shape
+    Ci = kernel.shape[2]
+    Hl, Wl = H2 // 2, W2 // 2
+    sel = {0: (1,), 1: (0, 1), 2: (0,)}
+    dzp = np.zeros((B, H2 + 2, W2 + 2, Co)); dzp[:, 1:H2 + 1, 1:W2 + 1] = dz      # index 2y - 1 + a  ->  2y + a
+    out = np.zeros((B, Hl, Wl, Ci))
+    for a in range(3):
+        for b in range(3):
+            weff = sum(kernel[ky, kx] for ky in sel[a] for kx in sel[b])         # (Ci, Co)
+            if round_w:
+                weff = bf16_round(weff.astype(np.float32))                         # prep_wt_k sums in fp32, prep_wb*_k rounds
+            out += np.einsum("bhwo,io->bhwi", dzp[:, a:a + 2 * Hl:2, b:b + 2 * Wl:2], weff)
+    return out
+
+
 @pytest.mark.parametrize("case", BF16_CASES)
 def test_bf16_storage_layer_local_rounding_is_exact(case, variant):
     B, H, W, C, sn, P, L, ic = case
@@ -543,6 +597,8 @@ def test_bf16_storage_layer_local_rounding_is_exact(case, variant):
             y = y * mask / (1.0 - cfg.dropout_rate)
         return y
 
+    from oct_image_segmentation_models_amd import _hip
+    mm = _hip.get_option("mfma_mode")
     inps = {}
     for li, spec in enumerate(plan):
         if spec.src == "input":
@@ -556,13 +612,20 @@ def test_bf16_storage_layer_local_rounding_is_exact(case, variant):
         else:
             inp = np.concatenate([act(li - 1), act(spec.skip_from)], axis=-1)
         inps[li] = inp
-        z = on.conv2d_same(inp, p64[li]["kernel"], p64[li]["bias"])
+        if bf16_fwd_operands(plan, li, cfg, mm):      # bf16 MFMA operands: activation and weights rounded, fp32 accumulate
+            z = on.conv2d_same(bf16_round(inp), bf16_round(p64[li]["kernel"]), p64[li]["bias"])
+        else:
+            z = on.conv2d_same(inp, p64[li]["kernel"], p64[li]["bias"])
         if spec.has_bn:
             err = np.abs(zh[li] - bf16_round(z))
             # + an absolute floor for cancelling sums near zero (the statistics differ by ~1e-5 relative)
             bound = 1.001 * bf16_ulp(z) + 5e-5 * np.abs(z).max()
-            assert (err <= bound).all(), (spec.name, (err / bound).max())
-            assert (err == 0).mean() > 0.995, (spec.name, (err == 0).mean())
+            # an operand whose fp32 activation sits on a bf16 rounding boundary may round the other way than this fp64
+            # model (a few per 1e5 elements): such an element moves its 9*cout outputs by up to |w| * ulp(x)
+            loose = bound + 2.0 ** -7 * np.abs(inp).max() * np.abs(p64[li]["kernel"]).max()
+            assert (err <= loose).all(), (spec.name, (err / loose).max())
+            assert (err <= bound).mean() > 0.999, (spec.name, (err <= bound).mean())
+            assert (err == 0).mean() > 0.99, (spec.name, (err == 0).mean())
         else:
             assert np.abs(probs.cpu().numpy() - on.softmax(z)).max() < 2e-4      # head arithmetic is fp32, unrounded
 
@@ -578,7 +641,9 @@ def test_bf16_storage_layer_local_rounding_is_exact(case, variant):
     skipraw = {}
     for li in range(nb - 1, -1, -1):
         spec, Lh = plan[li], eng.layers[li]
-        gx, dk, db = on._conv_backward(inps[li], p64[li]["kernel"], dzh[li])
+        wq = bf16_dx_weights(plan, li, mm)
+        gx, _, db = on._conv_backward(inps[li], bf16_round(p64[li]["kernel"]) if wq else p64[li]["kernel"], dzh[li])
+        _, dk, _ = on._conv_backward(bf16_round(inps[li]) if bf16_dw_operands(plan, li, mm) else inps[li], p64[li]["kernel"], dzh[li])
         gk = g[Lh["kernel_off"]:Lh["kernel_off"] + dk.size].reshape(dk.shape)
         assert np.linalg.norm(gk - dk) <= 1e-4 * np.linalg.norm(dk) + 1e-9, spec.name            # dW: fp32 accumulation
         gb = g[Lh["bias_off"]:Lh["bias_off"] + spec.cout]
@@ -593,8 +658,7 @@ def test_bf16_storage_layer_local_rounding_is_exact(case, variant):
         if spec.src == "prev":
             gq = bf16_round(alive * gx)
         elif spec.src == "up":
-            Bq, H2, W2, Cq = gx.shape
-            gy = gx.reshape(Bq, H2 // 2, 2, W2 // 2, 2, Cq).sum(axis=(2, 4))
+            gy = upconv_dx_effective(dzh[li], p64[li]["kernel"], wq)
             if plan[pi].name == f"mid.conv{L - 1}":
                 gy = gy * mask / (1.0 - cfg.dropout_rate)
             gq = bf16_round(alive * gy)
@@ -610,7 +674,8 @@ def test_bf16_storage_layer_local_rounding_is_exact(case, variant):
         pred = gr * (gq - c1_ - (zh[pi] - mean_) * rstd_ * c2_)
         err = np.abs(dzh[pi] - bf16_round(pred))
         bound = 1.001 * bf16_ulp(pred) + np.abs(gr) * bf16_ulp(gq) * (gq != 0) + 5e-5 * np.abs(pred).max()
-        assert (err <= bound).all(), (plan[pi].name, (err / bound).max())
+        assert (err <= bound).mean() > 0.999, (plan[pi].name, (err <= bound).mean())
+        assert (err <= 4 * bound).all(), (plan[pi].name, (err / bound).max())
         assert (err == 0).mean() > 0.99, (plan[pi].name, (err == 0).mean())
 
 

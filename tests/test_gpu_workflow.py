@@ -137,3 +137,38 @@ def test_train_model_with_focal_dice_loss(tmp_path):
     h = res.history
     assert len(h["loss"]) == 25 and np.isfinite(h["loss"]).all() and np.isfinite(h["val_loss"]).all()
     assert h["loss"][-1] < 0.7 * h["loss"][0]
+
+
+def test_batched_pipeline_equals_per_image_path_at_batch_128():
+    """BASELINE configs[4]: 256x512, device batch 128 (+ a ragged last batch) through evaluation/pipeline.py --
+    hipGraph replay, pinned double-buffered u8 upload, u8 arg-max + boundary-map download -- equals the per-image
+    forward bit for bit, and the pooled min-path post-process equals segment_maps run inline."""
+    from oct_image_segmentation_models_amd.common.synthetic import make_scans
+    from oct_image_segmentation_models_amd.engine import UNetEngine
+    from oct_image_segmentation_models_amd.evaluation.pipeline import BatchedPredictor
+    from oct_image_segmentation_models_amd.min_path_processing import graph_search
+    from oct_image_segmentation_models_amd.min_path_processing.pool import SegmentPool
+    Hh, Ww, Cc, B, N = 256, 512, 3, 128, 160
+    with SegmentPool((Hh, Ww), 1, workers=4) as pool:                 # workers before this test's engine exists
+        eng = UNetEngine(device="cuda:0", input_channels=1, num_classes=Cc, image_height=Hh, image_width=Ww, max_batch=B,
+                         training=False, seed=2, init_seed=4)
+        img8, _ = make_scans(8, Hh, Ww, Cc, seed=9)
+        imgs = np.concatenate([np.roll(img8, 5 * k, axis=2) for k in range(N // 8)], axis=0)
+        pred = BatchedPredictor(eng, B, want_maps=True)
+        got_lab = np.empty((N, Hh, Ww), np.uint8); got_map = np.empty((N, Cc - 1, Hh, Ww), np.uint8)
+        spans = []
+        for lo, hi, lab, maps in pred.run(imgs):
+            spans.append((lo, hi)); got_lab[lo:hi] = lab; got_map[lo:hi] = maps
+        assert spans == [(0, 128), (128, 160)]
+        for i in (0, 1, 77, 127, 128, 159):                            # per-image reference path
+            x = torch.from_numpy(imgs[i:i + 1]).cuda()
+            _, am = eng.forward(x, training=False, want_probs=False, want_argmax=True)
+            assert np.array_equal(am.cpu().numpy()[0], got_lab[i]), i
+            assert np.array_equal(eng.boundary_maps(am).cpu().numpy()[0], got_map[i]), i
+        again = list(pred.run(imgs[:B]))                               # the predictor is reusable
+        assert np.array_equal(again[0][2], got_lab[:B])
+        res = pool.segment(got_map[:6])
+        grid = graph_search.create_graph_structure((Ww, Hh), 1)
+        for i in range(6):
+            p_inline, e_inline, _ = graph_search.segment_maps(np.transpose(got_map[i], (0, 2, 1)), None, grid)
+            assert np.array_equal(res[i][0], p_inline) and np.array_equal(res[i][1], e_inline)
