@@ -36,6 +36,10 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {      // v_cvt_pk
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_hw{a, b}, bf16x2_hw));
 }
 
+// "use" a prefetched raw register set without doing anything: pins the compiler's s_waitcnt for those loads HERE
+__device__ __forceinline__ void touch_raw(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void touch_raw(uint2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+
 // 8 floats -> NS planes of 8 bf16 (a uint4 each); planes 1 and 2 hold the exact residuals
 template <int NS>
 __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&pl)[NS]) {
@@ -325,15 +329,20 @@ __global__ __launch_bounds__(kBlock, 1) void conv_bx_k(const IgemmArgs A) {
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky, ++g) {
             const bool last_row = ky == KH - 1, more = c + 1 < nch;
+            if (last_row && more) {
+                // The conversion below consumes the input registers requested two tap rows ago.  hipcc waits vmcnt(0)
+                // at their first use -- which would also wait for the weight DMA issued in THIS step (a full L2 round
+                // trip in front of the step's MFMAs).  Touch the registers first: the wait lands here, where nothing
+                // younger is in flight, and the DMA is issued behind it.
+#pragma unroll
+                for (int k = 0; k < NSLOT; ++k) { touch_raw(pin[k][0]); touch_raw(pin[k][1]); }
+                begin_store((c + 1) * 16);
+            }
             if (!last_row) dma_slab(c, ky + 1, (g + 1) & 1);
             else if (more) dma_slab(c + 1, 0, (g + 1) & 1);
             if (ky == 0 && more) load_in((c + 1) * 16);
-            if (last_row && more) {
-                begin_store((c + 1) * 16);
-                sweep_row(ky, g & 1, c & 1, std::true_type{}, (c + 1) & 1);
-            } else {
-                sweep_row(ky, g & 1, c & 1, std::false_type{}, 0);
-            }
+            if (last_row && more) sweep_row(ky, g & 1, c & 1, std::true_type{}, (c + 1) & 1);
+            else sweep_row(ky, g & 1, c & 1, std::false_type{}, 0);
             // an LDS-DMA becomes visible to other waves' ds_reads only through the issuing wave's vmcnt wait followed by
             // a barrier: drain explicitly (hipcc also does before __syncthreads() while a DMA is in flight)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -43,16 +43,38 @@ for counter, key in (("FETCH_SIZE", "fetch_kb"), ("WRITE_SIZE", "write_kb")):
         t[key] += float(r["Counter_Value"])
         if counter == "FETCH_SIZE":
             t["launches"] += 1
+import subprocess
+try:
+    commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:  # noqa: BLE001
+    commit = "unknown"
+try:
+    pmc_steps = int(open(os.path.join(src, "pmc_steps.txt")).read().strip())
+except (OSError, ValueError):
+    pmc_steps = None
 out = {}
 for k, t in traffic.items():
     n = max(t["launches"], 1)
     out[k] = {"launches_in_pass": t["launches"],
               "fetch_size_kb_per_launch": t["fetch_kb"] / n, "write_size_kb_per_launch": t["write_kb"] / n,
               "hbm_bytes_per_launch": (2.0 * t["fetch_kb"] + t["write_kb"]) / n * 1024.0}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1 "
-                   "--infer-batch 32`; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction); "
-                   "averages over all launches of a kernel instantiation in the pass (all layers it serves)",
-           "kernels": out}, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+fam = collections.defaultdict(lambda: dict(launches=0, bytes=0.0))
+total = 0.0
+for k, v in out.items():
+    f = fam[k.split("<")[0]]
+    f["launches"] += v["launches_in_pass"]; f["bytes"] += v["hbm_bytes_per_launch"] * v["launches_in_pass"]
+    total += v["hbm_bytes_per_launch"] * v["launches_in_pass"]
+families = {k: {"launches_in_pass": v["launches"], "hbm_bytes_per_launch": v["bytes"] / max(v["launches"], 1),
+                "hbm_bytes_per_step": (v["bytes"] / pmc_steps) if pmc_steps else None} for k, v in fam.items()}
+doc = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps N --warmup 0 --no-inference` "
+               "(train steps only; the pass also holds the one-off allocator / init kernels of torch, not counted: only oct:: "
+               "kernels); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)",
+       "commit": commit, "train_steps_in_pass": pmc_steps, "kernels": out, "families": families}
+if pmc_steps:
+    doc["train_step_hbm_bytes"] = total / pmc_steps
+json.dump(doc, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+if pmc_steps:
+    print(f"train-step HBM traffic: {total / pmc_steps / 1e9:.2f} GB/step over {pmc_steps} steps")
 
 rows = list(csv.DictReader(open(stats)))
 print(f"{'kernel':52s} {'calls':>6s} {'avg_us':>9s} {'total_ms':>9s} {'%':>6s} {'HBM MB/launch':>14s}")
