@@ -990,4 +990,227 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Backward-weights of the THIN layers on the bf16 pipe (v_mfma_f32_16x16x32_bf16): cin = CI and cout = CO in
+// {8, 16, 32}, not both 32 (those are conv_dwbx_k's).  K = 32 consecutive pixels of a row; both operands come out of
+// the channel-fastest LDS images [term][pixel][C] through the transposing read (4 pixels x 16 consecutive bf16 per 16
+// lanes).  "16 consecutive bf16" of a pixel row is what makes the thin shapes fit the 16-row / 16-column tile:
+//   * CI = 16: one A tile per tap (rows = ci);   CI = 32: two (ci 0-15, 16-31);
+//   * CI = 8:  the 16 values are (pixel, ci 0-7) and (pixel + 1, ci 0-7) = TWO horizontally adjacent taps in one tile:
+//     per kernel row the tiles (kx 0, kx 1) and (kx 2, -) -- 6 A tiles instead of 9;
+//   * CO = 8:  columns 8-15 of the B tile are dz of the next pixel: finite junk that is simply not written out.
+// Block = all channels of the layer for a strided list of 4-row x 32-pixel tiles; wave w owns pixel row w; staging is
+// branch-free (loads clamped, one tile ahead in registers, LDS images double buffered) so it is scheduled among the
+// MFMAs; fixed-order 4-wave sum, ONE partial slab per block.  grid (npb, 1, 1).
+// ------------------------------------------------------------------------------------------------------------------
+template <int KH, bool UP, int CI, int CO, int NS, typename AT>
+__global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(const ConvBwdWArgs A) {
+    constexpr int TH = 4, TW = 32, TAPS = KH * KH;
+    constexpr int IH = UP ? TH + 1 : TH + KH - 1, IW = UP ? TW + 1 : TW + KH - 1, PT = UP ? 0 : (KH - 1) / 2;
+    constexpr int NPX = IH * IW, NPD = TH * TW;
+    constexpr int OX = CI / 8, OD = CO / 8;                                   // channel octets per pixel
+    constexpr int PPX = kBlock / OX, NXS = (NPX + 4 + PPX - 1) / PPX, NPXP = NXS * PPX;      // (+4: junk taps read past the tile)
+    constexpr int PPD = kBlock / OD, NDS = (NPD + (CO == 8 ? 1 : 0) + PPD - 1) / PPD, NPDP = NDS * PPD;   // (+1: junk columns at CO = 8)
+    constexpr int XPB = CI * 2, DPB = CO * 2;                                 // bytes per pixel of a term's image
+    constexpr int XPL = NPXP * XPB, DPL = NPDP * DPB, BUF_B = NS * (XPL + DPL);
+    // A tiles: (tap group, column base); CI = 8 pairs horizontally adjacent taps
+    constexpr int MTX = CI == 8 ? (KH + 1) / 2 : KH * (CI / 16);              // tiles per kernel row
+    constexpr int MTILES = KH * MTX, NTILES = CO == 32 ? 2 : 1, NACC = MTILES * NTILES;
+    constexpr int RED_B = 4 * 256 * 4;
+    constexpr int SMEM_B = 2 * BUF_B > RED_B + kBlock * 8 * 4 ? 2 * BUF_B : RED_B + kBlock * 8 * 4;
+    __shared__ __attribute__((aligned(256))) char smem[SMEM_B];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Hs = UP ? A.H >> 1 : A.H, Ws = UP ? A.W >> 1 : A.W;
+
+    // ---- staging set-up ----
+    const int ox = tid % OX, cx = 8 * ox;
+    const bool two = (A.flags & F_TWO) && cx >= A.C0;
+    const int Cs = two ? A.C1 : A.C0, ccx = two ? cx - A.C0 : cx;
+    const AT* __restrict__ xsrc = (two ? reinterpret_cast<const AT*>(A.x1) : reinterpret_cast<const AT*>(A.x0)) + ccx;
+    const int od = tid % OD;
+    const AT* __restrict__ dsrc = reinterpret_cast<const AT*>(A.dz) + 8 * od;
+    const bool aff = (A.flags & F_AFF) != 0;
+    const float lo = aff ? 0.f : -3.0e38f;
+    float fa[8], fb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa[i] = 1.f; fb[i] = 0.f; }
+    if (aff) {
+        const float* ab = two ? A.ab1 : A.ab0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { fa[i] = ab[ccx + i]; fb[i] = ab[Cs + ccx + i]; }
+    }
+    int xly[NXS], xlx[NXS];
+#pragma unroll
+    for (int k = 0; k < NXS; ++k) {
+        const int P = tid / OX + k * PPX;
+        xly[k] = P < NPX ? P / IW : -1000000; xlx[k] = P % IW;               // pad pixels fall outside every image -> zeros
+    }
+    struct Regs { typename Raw4<AT>::type x[NXS][2], d[NDS][2]; };
+    float bsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+
+    auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
+        b = tl / A.tiles; const int t = tl % A.tiles;
+        x0 = (t % A.tiles_x) * TW; y0 = (t / A.tiles_x) * TH;
+    };
+    auto load = [&](int tl, Regs& R) {                                       // unconditional: addresses clamped into the image
+        int b, y0, x0; tile_of(tl, b, y0, x0);
+#pragma unroll
+        for (int k = 0; k < NXS; ++k) {
+            int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;
+            gy = gy < 0 ? 0 : (gy >= A.H ? A.H - 1 : gy); gx = gx < 0 ? 0 : (gx >= A.W ? A.W - 1 : gx);
+            const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
+            const AT* p = xsrc + (((size_t)b * Hs + sy) * Ws + sx) * Cs;
+            R.x[k][0] = ldraw4<AT>(p); R.x[k][1] = ldraw4<AT>(p + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NDS; ++k) {
+            const int P = tid / OD + k * PPD;
+            int py = y0 + P / TW, px = x0 + P % TW;
+            py = py >= A.H ? A.H - 1 : py; px = px >= A.W ? A.W - 1 : px;
+            const AT* p = dsrc + (((size_t)b * A.H + py) * A.W + px) * A.Cout;
+            R.d[k][0] = ldraw4<AT>(p); R.d[k][1] = ldraw4<AT>(p + 4);
+        }
+    };
+    auto store = [&](int tl, const Regs& R, int buf, bool live) {
+        int b, y0, x0; tile_of(tl, b, y0, x0);
+        char* const Xb = smem + buf * BUF_B + cx * 2;
+        char* const Db = smem + buf * BUF_B + NS * XPL + od * 16;
+#pragma unroll
+        for (int k = 0; k < NXS; ++k) {
+            const float4 v0 = widen4(R.x[k][0]), v1 = widen4(R.x[k][1]);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;
+            const bool in = gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {      // out-of-range stays exactly zero (padding is applied after the activation)
+                const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);
+                v[i] = in ? y : 0.f;
+            }
+            if (A.flags & F_DROP) {            // (only the up-conv behind the bottleneck: a uniform, rarely taken branch)
+                const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
+                const uint32_t el = (uint32_t)((((size_t)b * Hs + sy) * Ws + sx) * Cs + ccx);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = in ? v[i] * drop_mul(A.drop, el + i) : 0.f;
+            }
+            uint4 pl[NS];
+            split8<NS>(v, pl);
+            const int P = tid / OX + k * PPX;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(Xb + P * XPB + p * XPL) = pl[p];
+        }
+#pragma unroll
+        for (int k = 0; k < NDS; ++k) {
+            const int P = tid / OD + k * PPD;
+            const bool in = live && P < NPD && y0 + P / TW < A.H && x0 + P % TW < A.W;
+            const float4 v0 = widen4(R.d[k][0]), v1 = widen4(R.d[k][1]);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[i] = in ? v[i] : 0.f; bsum[i] += v[i]; }
+            uint4 pl[NS];
+            split8<NS>(v, pl);
+#pragma unroll
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(Db + P * DPB + p * DPL) = pl[p];
+        }
+    };
+
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposing-read lane geometry: lanes 16 kg .. 16 kg + 15 read the 4 pixels x 16 values block at pixel rows
+    // 8 kg + 4 t + q (q = (lane & 15) >> 2), values 4 p .. 4 p + 3 (p = lane & 3); lane receives value (lane & 15)
+    const int kgq = 8 * (lane >> 4) + ((lane & 15) >> 2), p4 = 4 * (lane & 3);
+    const int xlane = kgq * XPB + p4 * 2, dlane = kgq * DPB + p4 * 2;
+    auto trx = [&](const char* base, int pitch) -> bf16x8 {
+        const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base));
+        const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * pitch));
+        return bf16x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    };
+    auto compute = [&](int buf) {
+        const char* Xl = smem + buf * BUF_B + xlane;
+        const char* Dl = smem + buf * BUF_B + NS * XPL + dlane + (wave * TW) * DPB;
+        bf16x8 bv[NTILES][NS];
+#pragma unroll
+        for (int nt = 0; nt < NTILES; ++nt)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) bv[nt][p] = trx(Dl + p * DPL + nt * 32, DPB);
+#pragma unroll
+        for (int mt = 0; mt < MTILES; ++mt) {
+            const int ky = mt / MTX, mx = mt % MTX;
+            const int kx = CI == 8 ? 2 * mx : mx / (CI / 16), cb = CI == 8 ? 0 : (mx % (CI / 16)) * 16;   // tap column, channel base
+            bf16x8 a[NS];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) a[p] = trx(Xl + p * XPL + ((wave + ky) * IW + kx) * XPB + cb * 2, XPB);
+#pragma unroll
+            for (int nt = 0; nt < NTILES; ++nt) {
+                f32x4 c = acc[mt * NTILES + nt];
+                if constexpr (NS == 3) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bv[nt][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bv[nt][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bv[nt][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bv[nt][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bv[nt][0], c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bv[nt][0], c, 0, 0, 0);
+                acc[mt * NTILES + nt] = c;
+            }
+        }
+    };
+
+    Regs R;
+    const int t0 = blockIdx.x, step = A.npb, tend = A.total_tiles, tlast = tend - 1;
+    if (t0 < tend) {
+        load(t0, R);
+        store(t0, R, 0, true);
+        load(t0 + step < tend ? t0 + step : tlast, R);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int tl = t0; tl < tend; tl += step, buf ^= 1) {
+        const int t1 = tl + step, t2 = tl + 2 * step;
+        store(t1 < tend ? t1 : tlast, R, buf ^ 1, t1 < tend);
+        load(t2 < tend ? t2 : tlast, R);
+        compute(buf);
+        __syncthreads();
+    }
+
+    // ---- 4-wave sum, tile by tile, through LDS (fixed order), then the slab; bias gradient = column sums of dz ----
+    float* const red = reinterpret_cast<float*>(smem);
+    const size_t wsize = (size_t)TAPS * A.Cin * A.Cout;
+    float* out = A.part + (size_t)blockIdx.x * (wsize + A.Cout);
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) {
+        const int mt = t / NTILES, nt = t % NTILES, ky = mt / MTX, mx = mt % MTX;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+        {
+            const int r = tid >> 6, ln = tid & 63;                           // 256 threads = 4 regs x 64 lanes
+            const float sv = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+            const int col = ln & 15, row = 4 * (ln >> 4) + r;
+            int kx, ci;
+            if constexpr (CI == 8) { kx = 2 * mx + (row >> 3); ci = row & 7; }
+            else { kx = mx / (CI / 16); ci = (mx % (CI / 16)) * 16 + row; }
+            const int co = nt * 16 + col;
+            if (kx < KH && co < CO)
+                out[((size_t)(ky * KH + kx) * A.Cin + ci) * A.Cout + co] = sv;
+        }
+    }
+    __syncthreads();
+    float* const bs = red + 1024;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bs[tid * 8 + i] = bsum[i];
+    __syncthreads();
+    if (tid < CO) {
+        const int oct = tid >> 3, comp = tid & 7;
+        float sv = 0.f;
+        for (int t = oct; t < kBlock; t += OD) sv += bs[t * 8 + comp];
+        out[wsize + tid] = sv;
+    }
+}
+
 }  // namespace oct

@@ -30,6 +30,7 @@ int g_igemm_min_blocks = 512;     // a layer takes the taller pixel tile only if
 int g_dwpair8 = 1;                // 3x3 layers with 8 output channels: pixel-pair backward-weights kernel (0 = padded 16-column kernel)
 int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
+int g_dwbt_f32_all = 0;            // 1: fp32 mode also takes conv_dwbt_k for every thin shape (tests exercise all instantiations)
 int g_bt_blocks_per_cu = 0;        // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows: 3 / 2 / 1 at 8 / 16 / 32 input channels)
 int g_dwbx_blocks = 256;           // target grid of a bf16-pipe backward-weights launch (1 block per CU: the kernel needs most of the LDS)
 int g_bx_min_blocks = 256;         // a bf16-pipe launch takes the taller pixel tile only if that still yields this many blocks
@@ -185,9 +186,19 @@ inline bool bt_k_ok(int k) { return k == 8 || k == 16 || k == 32; }
 inline bool bt_fwd_ok(const Layer& l) { return l.src != SRC_INPUT && l.has_bn && l.cout <= 16 && l.cout % 4 == 0 && bt_k_ok(l.cin); }
 inline bool bt_bwd_ok(const Layer& l) { const int cg = bx_bwd_cg(l); return l.src != SRC_INPUT && l.has_bn && cg <= 16 && cg % 4 == 0 && bt_k_ok(l.cout); }
 
+// thin backward-weights on the bf16 pipe (conv_dwbt_k): the instantiated (cin, cout) pairs
+inline bool dwbt_ok(const Layer& l) {
+    if (l.src == SRC_INPUT || l.kh == 1 || !l.has_bn) return false;
+    const int ci = l.cin, co = l.cout;
+    if (l.src == SRC_UP) return (ci == 16 && co == 8) || (ci == 32 && co == 16);
+    if (l.src == SRC_CONCAT && (l.cin / 2) % 8) return false;         // staging moves 8-channel octets: one source tensor each
+    return (ci == 8 && co == 8) || (ci == 8 && co == 16) || (ci == 16 && co == 8) || (ci == 16 && co == 16) ||
+           (ci == 16 && co == 32) || (ci == 32 && co == 16);
+}
+
 // dW plan: which kernel handles a layer, its channel chunking, pixel-tile height and pixel-block count
 struct DwPlan { int kind;  /* 0 = VALU (1-channel input / head), 16, 32, 33 = bf16 pipe (conv_dwbx_k) */ int cic, coc, th, chunks, npb, tiles; };
-DwPlan dw_plan(const Layer& l, int B, int mfma_mode) {
+DwPlan dw_plan(const Layer& l, int B, int mfma_mode, int bf16) {
     DwPlan p{};
     if (mfma_mode && l.src != SRC_INPUT && l.kh != 1 && l.cin % 32 == 0 && l.cout % 32 == 0) {
         // wide layers on the bf16 pipe: one block per (32 ci, 32 co) pair and pixel slice, ~1 block per CU in total
@@ -195,6 +206,15 @@ DwPlan dw_plan(const Layer& l, int B, int mfma_mode) {
         p.chunks = (l.cin / 32) * (l.cout / 32);
         p.tiles = cdiv(l.H, p.th) * cdiv(l.W, kTileX);
         p.npb = std::max(1, std::min(B * p.tiles, cdiv(g_dwbx_blocks, p.chunks)));
+        return p;
+    }
+    // fp32 mode: the three-term split of both operands makes conv_dwbt_k VALU-bound; it only beats the fp32-pipe kernels
+    // at 16 input channels (measured per shape, B=32 256x512).  bf16 mode (one rounding, one product): every thin shape.
+    if (mfma_mode && dwbt_ok(l) && (bf16 || g_dwbt_f32_all || (l.src != SRC_UP && l.cin == 16 && l.cout >= 16))) {
+        // thin layers on the bf16 pipe (conv_dwbt_k): one block holds all channels; 1 or 2 blocks per CU (LDS images)
+        p.kind = 34; p.cic = l.cin; p.coc = l.cout; p.th = 4; p.chunks = 1;
+        p.tiles = cdiv(l.H, p.th) * cdiv(l.W, kTileX);
+        p.npb = std::max(1, std::min(B * p.tiles, 256 * (l.cin + l.cout >= 48 ? 1 : 2)));
         return p;
     }
     if (l.src == SRC_INPUT || l.cin % 4 || l.cout % 4 || l.kh == 1) {
@@ -263,7 +283,7 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
         if (c.training) {
             const size_t wsz = (size_t)l.kh * l.kw * l.cin * l.cout + l.cout;
             const size_t rows = l.src == SRC_HEAD ? (size_t)(2048 + c.max_batch)
-                                                  : (size_t)std::max(dw_plan(l, c.max_batch, 0).npb, dw_plan(l, c.max_batch, 1).npb);
+                                                  : (size_t)std::max(dw_plan(l, c.max_batch, 0, 0).npb, std::max(dw_plan(l, c.max_batch, 1, 1).npb, dw_plan(l, c.max_batch, 1, 0).npb));
             float* dwp = (float*)take(rows * wsz * 4);
             if (base) { l.dwp = dwp; l.dw_rows = (int)rows; }
             dw_max = 0;
@@ -717,7 +737,7 @@ int flush_reduce(oct_unet* h, hipStream_t s) {
 int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const void* dz, int B, hipStream_t s) {
     const Layer& l = h->plan.L[li];
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
-    DwPlan p = dw_plan(l, B, g_mfma_mode);
+    DwPlan p = dw_plan(l, B, g_mfma_mode, h->cfg.dtype);
     p.npb = std::min(p.npb, l.dw_rows);
     ConvBwdWArgs a{};
     a.x0 = sd.x0; a.ab0 = sd.ab0; a.C0 = sd.C0; a.x1 = sd.x1; a.ab1 = sd.ab1; a.C1 = sd.C1;
@@ -742,6 +762,18 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
         HIP_OK(hipGetLastError());
     } else if (p.kind == 0) {
         rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by);   // other 1-channel / odd-channel first layers
+    } else if (p.kind == 34) {
+        const int bf = a.act_bf16 ? 1 : 0;
+        char nm[64]; snprintf(nm, sizeof nm, "conv_dwbt_k<%d,%s,%d,%d,%d,%s>", l.kh, up ? "true" : "false", l.cin, l.cout, bf ? 1 : 3, AT_NAME(bf));
+        ProfScope ps(s, nm, l.name, fl, by);
+#define DWBT(KHV, UPV, CI, CO) if (l.cin == CI && l.cout == CO) { \
+            if (bf) conv_dwbt_k<KHV, UPV, CI, CO, 1, bf16_t><<<p.npb, kBlock, 0, s>>>(a); \
+            else conv_dwbt_k<KHV, UPV, CI, CO, 3, float><<<p.npb, kBlock, 0, s>>>(a); }
+        if (up) { DWBT(2, true, 16, 8) else DWBT(2, true, 32, 16) else return fail(-3, "conv_dwbt_k: up-conv shape not instantiated"); }
+        else { DWBT(3, false, 8, 8) else DWBT(3, false, 8, 16) else DWBT(3, false, 16, 8) else DWBT(3, false, 16, 16)
+               else DWBT(3, false, 16, 32) else DWBT(3, false, 32, 16) else return fail(-3, "conv_dwbt_k: shape not instantiated"); }
+#undef DWBT
+        HIP_OK(hipGetLastError());
     } else if (p.kind == 33) {
         dim3 grid(p.npb, l.cin / 32, l.cout / 32), block(kBlock);
         const int bf = a.act_bf16 ? 1 : 0;
@@ -1238,7 +1270,7 @@ const Opt k_opts[] = {
     {"dw16_blocks", &g_dw16_blocks, 64}, {"igemm_persistent_blocks", &g_igemm_p_blocks, 8},
     {"igemm_min_blocks", &g_igemm_min_blocks, 1}, {"dwpair8_enable", &g_dwpair8, 0},
     {"pair8_geometry", &g_pair_geo, 111}, {"pair8_min_tiles", &g_pair_min_tiles, 1}, {"thin8_min_tiles", &g_thin_min_tiles, 1},
-    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0},
+    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0}, {"dwbt_f32_all", &g_dwbt_f32_all, 0},
 };
 }  // namespace
 
@@ -1264,6 +1296,7 @@ int oct_set_option(const char* name, int value) {
     if (!strcmp(name, "bx_min_blocks")) { g_bx_min_blocks = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "dwbx_blocks")) { g_dwbx_blocks = value < 8 ? 8 : value; return 0; }
     if (!strcmp(name, "bt_blocks_per_cu")) { g_bt_blocks_per_cu = value < 0 ? 0 : value; return 0; }
+    if (!strcmp(name, "dwbt_f32_all")) { g_dwbt_f32_all = value ? 1 : 0; return 0; }
     return fail(-1, std::string("unknown option: ") + name);
 }
 

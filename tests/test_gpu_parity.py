@@ -55,7 +55,7 @@ DROP_STEP = 3
 
 
 @pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111", "dw16_padded",
-                        "bx_tall", "f32_pipe"])
+                        "bx_tall", "f32_pipe", "dwbt_all"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant: for the thin layers the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels (otherwise only chosen on large grids); for the wide layers the
@@ -65,6 +65,7 @@ def variant(request):
     v = request.param
     _hip.set_option("bx_min_blocks", 1 if v == "bx_tall" else 256)
     _hip.set_option("mfma_mode", 0 if v == "f32_pipe" else 1)
+    _hip.set_option("dwbt_f32_all", 1 if v == "dwbt_all" else 0)     # fp32 mode: every thin dW shape on the bf16 pipe
     _hip.set_option("igemm_persistent_min_tiles", 1 if v == "persistent" else 1 << 30)
     _hip.set_option("thin8_min_tiles", 1 if v == "thin8_valu" or v.startswith("pair8") else 1 << 30)
     _hip.set_option("pair8_min_tiles", 1 if v.startswith("pair8") else 1 << 30)
@@ -73,6 +74,7 @@ def variant(request):
     yield v
     _hip.set_option("bx_min_blocks", 256)
     _hip.set_option("mfma_mode", 1)
+    _hip.set_option("dwbt_f32_all", 0)
     _hip.set_option("dwpair8_enable", 1)
     _hip.set_option("igemm_persistent_min_tiles", 2048)
     _hip.set_option("thin8_min_tiles", 2048)
@@ -549,7 +551,16 @@ def bf16_dx_weights(plan, li, mfma_mode):
 
 def bf16_dw_operands(plan, li, mfma_mode):
     sp = plan[li]
-    return bool(mfma_mode) and sp.src != "input" and sp.kh != 1 and sp.cin % 32 == 0 and sp.cout % 32 == 0
+    if not mfma_mode or sp.src == "input" or sp.kh == 1 or not sp.has_bn:
+        return False
+    if sp.cin % 32 == 0 and sp.cout % 32 == 0:                               # conv_dwbx_k
+        return True
+    pair = (sp.cin, sp.cout)                                                  # conv_dwbt_k's instantiated shapes
+    if sp.src == "up":
+        return pair in ((16, 8), (32, 16))
+    if sp.src == "concat" and (sp.cin // 2) % 8:
+        return False
+    return pair in ((8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16))
 
 
 def upconv_dx_effective(dz, kernel, round_w):
