@@ -119,15 +119,18 @@ __host__ inline size_t wbx_bytes(int KH, int Kc, int M, int MB, int NS) {
 // half-slot hh ^ ((r >> 3) & 1) -- prep_wbx_k swizzles the weights the same way -- which separates every such pair for
 // any tap shift of the pixel rows: conflict-free fragment reads.
 // ------------------------------------------------------------------------------------------------------------------
-template <int KH, int AMODE, int EPI, int TH, int MB, int NS, bool DROP, typename AT>
-__global__ __launch_bounds__(kBlock, 1) void conv_bx_k(const IgemmArgs A) {
-    constexpr int TW = 32, MTW = MB / 32, NTW = TH / 4, ACC = 16, QUADS = 4, MT = 32;
-    static_assert(TH % 4 == 0 && (MB == 32 || MB == 64), "tile geometry");
+// NW = waves per block: 4 (one per SIMD) or 8 (two per SIMD: the conversion / LDS phases of one wave run under the MFMAs
+// of its SIMD partner; each wave then owns TH / 8 pixel rows).
+template <int KH, int AMODE, int EPI, int TH, int MB, int NS, bool DROP, int NW, typename AT>
+__global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
+    constexpr int NTHR = 64 * NW;
+    constexpr int TW = 32, MTW = MB / 32, NTW = TH / NW, ACC = 16, QUADS = 4, MT = 32;
+    static_assert(TH % NW == 0 && NTW >= 1 && (MB == 32 || MB == 64), "tile geometry");
     constexpr int IH = AMODE == A_NORMAL ? TH + KH - 1 : (AMODE == A_UPF ? TH / 2 + 1 : 2 * TH + 1);
     constexpr int IW = AMODE == A_NORMAL ? TW + KH - 1 : (AMODE == A_UPF ? TW / 2 + 1 : 2 * TW + 1);
     constexpr int NPIX = IH * IW;
-    constexpr int NSLOT = (NPIX * 2 + kBlock - 1) / kBlock;    // staging items (pixel, 8-channel half) per thread
-    constexpr int NPIXP = NSLOT * (kBlock / 2);                // image padded to whole slots: every item has a home, so
+    constexpr int NSLOT = (NPIX * 2 + NTHR - 1) / NTHR;    // staging items (pixel, 8-channel half) per thread
+    constexpr int NPIXP = NPIX + 64;                           // + a 64-pixel dump strip: items past the tile land there, so
                                                                // the conversion is branch-free (schedulable among MFMAs)
     constexpr int PLANE_B = NPIXP * 32;                        // bytes of one term's image
     constexpr int IN_B = NS * PLANE_B;                         // one buffer
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(kBlock, 1) void conv_bx_k(const IgemmArgs A) {
     static_assert(SLAB_B % 1024 == 0, "slab must be a whole number of DMA pieces");
     constexpr int MAXC = AMODE == A_DOWN2 ? 256 : 512;         // affine rows cached in LDS (K channels; launcher checks)
     constexpr int EPI_B = EPI == EPI_MASK ? 4 * MB * 4 : MB * 4;
-    constexpr int RED_B = 4 * 2 * MTW * MT * 4;
+    constexpr int RED_B = NW * 2 * MTW * MT * 4;
     constexpr int SCRATCH_B = (EPI_B + RED_B) > 2 * SLAB_B ? (EPI_B + RED_B) : 2 * SLAB_B;
 
     __shared__ __attribute__((aligned(1024))) char smem[2 * IN_B + SCRATCH_B + 2 * MAXC * 4];
@@ -167,8 +170,8 @@ __global__ __launch_bounds__(kBlock, 1) void conv_bx_k(const IgemmArgs A) {
         const char* g = wsrc + (((size_t)chunk * nmb + mblk) * KH + ky) * SLAB_B + lane * 16;
         char* l = WTs + slot * SLAB_B;
 #pragma unroll
-        for (int p = 0; p < (PIECES + 3) / 4; ++p) {
-            const int piece = wave + 4 * p;
+        for (int p = 0; p < (PIECES + NW - 1) / NW; ++p) {
+            const int piece = wave + NW * p;
             if (piece < PIECES)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + piece * 1024),
                                                  (__attribute__((address_space(3))) void*)(l + piece * 1024), 16, 0, 0);
@@ -180,16 +183,17 @@ __global__ __launch_bounds__(kBlock, 1) void conv_bx_k(const IgemmArgs A) {
     const int hh = tid & 1;
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
-        const int P = (tid >> 1) + k * (kBlock / 2), lx = P % IW, ly = P / IW, gy = iy0 + ly, gx = ix0 + lx;
+        const int P = (tid >> 1) + k * (NTHR / 2), lx = P % IW, ly = P / IW, gy = iy0 + ly, gx = ix0 + lx;
         const bool in = P < NPIX && gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi;
         goff[k] = in ? gy * A.Wi + gx : -1;
-        ldst[k] = P * 32 + ((hh ^ ((P >> 3) & 1)) * 16);         // P < NPIXP always (pad pixels receive zeros)
+        const int Pd = P < NPIX ? P : NPIX + (P & 63);            // items past the tile: spread over the dump strip
+        ldst[k] = Pd * 32 + ((hh ^ ((Pd >> 3) & 1)) * 16);
     }
     const size_t img = (size_t)b * A.Hi * A.Wi;
     // affine rows of the (possibly concatenated) input, once per block: (a, b) of y = max(a*z + b, lo); identity without BN
     const bool aff = (A.flags & F_AFF) != 0;
     const float lo = aff ? 0.f : -3.0e38f;
-    for (int c = tid; c < nch * 16; c += kBlock) {
+    for (int c = tid; c < nch * 16; c += NTHR) {
         float av = 1.f, bv = 0.f;
         if (aff && c < A.Cin) {
             const bool two = (A.flags & F_TWO) && c >= A.C0;
@@ -354,9 +358,9 @@ __global__ __launch_bounds__(kBlock, 1) void conv_bx_k(const IgemmArgs A) {
     float* const epi = reinterpret_cast<float*>(WTs);
     float* const red = reinterpret_cast<float*>(WTs + EPI_B);
     if constexpr (EPI == EPI_FWD) {
-        for (int e = tid; e < MB; e += kBlock) epi[e] = m0 + e < A.Mout ? A.bias[A.m_off + m0 + e] : 0.f;
+        for (int e = tid; e < MB; e += NTHR) epi[e] = m0 + e < A.Mout ? A.bias[A.m_off + m0 + e] : 0.f;
     } else if constexpr (EPI == EPI_MASK) {
-        for (int e = tid; e < 4 * MB; e += kBlock) {
+        for (int e = tid; e < 4 * MB; e += NTHR) {
             const int arr = e / MB, m = m0 + e % MB;
             epi[e] = m < A.Mout ? A.bnin[arr * A.Mout + m] : 0.f;
         }
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(kBlock, 1) void conv_bx_k(const IgemmArgs A) {
                 const int stat = tid / MB, ml = tid % MB, mt = ml / MT, mloc = ml % MT;
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) s += red[((w * 2 + stat) * MTW + mt) * MT + mloc];
+                for (int w = 0; w < NW; ++w) s += red[((w * 2 + stat) * MTW + mt) * MT + mloc];
                 if (m0 + ml < A.Mout)
                     A.part[((size_t)b * A.tiles + tile) * (2 * A.Mout) + (size_t)stat * A.Mout + m0 + ml] = s;
             }

@@ -30,6 +30,7 @@ int g_igemm_min_blocks = 512;     // a layer takes the taller pixel tile only if
 int g_dwpair8 = 1;                // 3x3 layers with 8 output channels: pixel-pair backward-weights kernel (0 = padded 16-column kernel)
 int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
+int g_bx_waves = 8;                // waves per block of conv_bx_k where the tile has >= 8 rows: 8 = two per SIMD, 4 = one per SIMD
 int g_dwbt_f32_all = 0;            // 1: fp32 mode also takes conv_dwbt_k for every thin shape (tests exercise all instantiations)
 int g_bt_blocks_per_cu = 0;        // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows: 3 / 2 / 1 at 8 / 16 / 32 input channels)
 int g_dwbx_blocks = 256;           // target grid of a bf16-pipe backward-weights launch (1 block per CU: the kernel needs most of the LDS)
@@ -431,27 +432,34 @@ int launch_thin8(IgemmArgs a, int B, hipStream_t s, const char* layer, double fl
 }
 
 // ---- bf16-pipe implicit GEMM (kernels_bx.hpp): NS = 3 split products in fp32 mode, 1 in bf16 mode ----
-template <int KH, int AMODE, int EPI, int TH, int MB>
-int launch_bx_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+template <int KH, int AMODE, int EPI, int TH, int MB, int NW>
+int launch_bx_nw(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
     a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH);
-    dim3 grid(a.tiles, cdiv(a.Mout, MB), B), block(kBlock);
-    char nm[64]; snprintf(nm, sizeof nm, "conv_bx_k<%d,%d,%d,%d,%d,%d,%s>", KH, AMODE, EPI, TH, MB, a.act_bf16 ? 1 : 3, AT_NAME(a.act_bf16));
+    dim3 grid(a.tiles, cdiv(a.Mout, MB), B), block(64 * NW);
+    char nm[64]; snprintf(nm, sizeof nm, "conv_bx_k<%d,%d,%d,%d,%d,%d,%d,%s>", KH, AMODE, EPI, TH, MB, a.act_bf16 ? 1 : 3, NW, AT_NAME(a.act_bf16));
     ProfScope ps(s, nm, layer, flops, bytes);
     if constexpr (AMODE == A_UPF && EPI == EPI_FWD) {
         if (a.flags & F_DROP) {
-            if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, true, bf16_t><<<grid, block, 0, s>>>(a);
-            else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, true, float><<<grid, block, 0, s>>>(a);
+            if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, true, NW, bf16_t><<<grid, block, 0, s>>>(a);
+            else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, true, NW, float><<<grid, block, 0, s>>>(a);
             HIP_OK(hipGetLastError());
             *rows = B * a.tiles;
             return 0;
         }
     }
     if (a.flags & F_DROP) return fail(-3, "conv_bx_k: dropout on the input is only built for the up-conv forward");
-    if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, false, bf16_t><<<grid, block, 0, s>>>(a);
-    else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, false, float><<<grid, block, 0, s>>>(a);
+    if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, false, NW, bf16_t><<<grid, block, 0, s>>>(a);
+    else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, false, NW, float><<<grid, block, 0, s>>>(a);
     HIP_OK(hipGetLastError());
     *rows = B * a.tiles;
     return 0;
+}
+template <int KH, int AMODE, int EPI, int TH, int MB>
+int launch_bx_geo(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
+    if constexpr (TH % 8 == 0) {
+        if (g_bx_waves == 8) return launch_bx_nw<KH, AMODE, EPI, TH, MB, 8>(a, B, s, layer, flops, bytes, rows);
+    }
+    return launch_bx_nw<KH, AMODE, EPI, TH, MB, 4>(a, B, s, layer, flops, bytes, rows);
 }
 template <int KH, int AMODE, int EPI>
 int launch_bx(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
@@ -1270,7 +1278,7 @@ const Opt k_opts[] = {
     {"dw16_blocks", &g_dw16_blocks, 64}, {"igemm_persistent_blocks", &g_igemm_p_blocks, 8},
     {"igemm_min_blocks", &g_igemm_min_blocks, 1}, {"dwpair8_enable", &g_dwpair8, 0},
     {"pair8_geometry", &g_pair_geo, 111}, {"pair8_min_tiles", &g_pair_min_tiles, 1}, {"thin8_min_tiles", &g_thin_min_tiles, 1},
-    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0}, {"dwbt_f32_all", &g_dwbt_f32_all, 0},
+    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0}, {"dwbt_f32_all", &g_dwbt_f32_all, 0}, {"bx_waves", &g_bx_waves, 4},
 };
 }  // namespace
 
@@ -1297,6 +1305,7 @@ int oct_set_option(const char* name, int value) {
     if (!strcmp(name, "dwbx_blocks")) { g_dwbx_blocks = value < 8 ? 8 : value; return 0; }
     if (!strcmp(name, "bt_blocks_per_cu")) { g_bt_blocks_per_cu = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "dwbt_f32_all")) { g_dwbt_f32_all = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "bx_waves")) { if (value != 4 && value != 8) return fail(-1, "bx_waves must be 4 or 8"); g_bx_waves = value; return 0; }
     return fail(-1, std::string("unknown option: ") + name);
 }
 

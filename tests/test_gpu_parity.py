@@ -55,7 +55,7 @@ DROP_STEP = 3
 
 
 @pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111", "dw16_padded",
-                        "bx_tall", "f32_pipe", "dwbt_all"])
+                        "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant: for the thin layers the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels (otherwise only chosen on large grids); for the wide layers the
@@ -63,7 +63,8 @@ def variant(request):
     ("bx_tall": tiles larger than the image, ragged everywhere) and the fp32-pipe kernels ("f32_pipe": mfma_mode 0)."""
     from oct_image_segmentation_models_amd import _hip
     v = request.param
-    _hip.set_option("bx_min_blocks", 1 if v == "bx_tall" else 256)
+    _hip.set_option("bx_min_blocks", 1 if v.startswith("bx_tall") else 256)
+    _hip.set_option("bx_waves", 4 if v == "bx_tall_w4" else 8)
     _hip.set_option("mfma_mode", 0 if v == "f32_pipe" else 1)
     _hip.set_option("dwbt_f32_all", 1 if v == "dwbt_all" else 0)     # fp32 mode: every thin dW shape on the bf16 pipe
     _hip.set_option("igemm_persistent_min_tiles", 1 if v == "persistent" else 1 << 30)
@@ -73,6 +74,7 @@ def variant(request):
     _hip.set_option("dwpair8_enable", 0 if v == "dw16_padded" else 1)
     yield v
     _hip.set_option("bx_min_blocks", 256)
+    _hip.set_option("bx_waves", 8)
     _hip.set_option("mfma_mode", 1)
     _hip.set_option("dwbt_f32_all", 0)
     _hip.set_option("dwpair8_enable", 1)
