@@ -50,8 +50,9 @@ typedef struct oct_unet_cfg {
     int conv_layers;      /* default 2                            (unet.py:71)          */
     int enc_k;            /* 3  (enc_kernel (3,3))                (unet.py:72)          */
     int dec_k;            /* 2  (dec_kernel (2,2))                (unet.py:73)          */
-    int dtype;            /* 0 = f32; 1 = bf16 STORAGE of activations / activation gradients,   */
-                          /*     f32 arithmetic, f32 BN statistics, f32 parameters + gradients  */
+    int dtype;            /* 0 = f32; 1 = bf16 activations / activation gradients (storage AND, */
+                          /*     with mfma_mode 1, MFMA operands), f32 accumulation, f32 BN     */
+                          /*     statistics, f32 parameters + gradients (BASELINE configs[2])   */
     int training;         /* 1: workspace also holds saved activations + gradients      */
     float bn_eps;         /* 1e-3  keras BatchNormalization default                     */
     float bn_momentum;    /* 0.99                                                       */
@@ -160,7 +161,19 @@ int oct_unet_profile_end(oct_unet* h, oct_profile_entry* out, int max_entries, i
 int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int n_cls, int bg_ilm, int bg_csi,
                       unsigned char* maps_dev, oct_stream_t stream);
 
-/* ---- tuning knobs (process-wide; results do not depend on them, only which kernel variant runs) ----
+/* ---- options (process-wide) ----
+ * Two select ARITHMETIC (documented alternatives, each tested against the oracle):
+ *   "mfma_mode" (default 1): 1 = convolutions on the bf16 matrix pipe -- in fp32 mode (cfg.dtype 0) every fp32 operand is
+ *   split exactly into three bf16 terms and a product is six bf16 MFMAs accumulated in fp32 (fp32-equivalent results,
+ *   DESIGN.md section 4); in bf16 mode (cfg.dtype 1) activations and weights are rounded once and multiplied directly.
+ *   0 = the fp32-pipe kernels (v_mfma_f32_*_f32), fp32 math on whatever the storage type is.
+ *   "focal_clip_modulation" (default 0): see oct_unet_set_focal_dice.
+ * The rest are tuning knobs (results do not depend on them beyond fp32 rounding, only which kernel variant runs):
+ *   "bx_min_blocks" (256): a wide bf16-pipe launch takes the taller pixel tile only if that still yields this many blocks.
+ *   "bx_waves" (8 | 4): waves per block of conv_bx_k where the tile has >= 8 rows (two / one per SIMD).
+ *   "dwbx_blocks" (256): grid target of the wide bf16-pipe backward-weights kernel.
+ *   "bt_blocks_per_cu" (0 = as many as the LDS images allow): persistent blocks of the thin bf16-pipe kernel.
+ *   "dwbt_f32_all" (0): 1 = fp32 mode takes conv_dwbt_k for every thin backward-weights shape (default: where it wins).
  *   "igemm_persistent_min_tiles" (default 2048): number of pixel tiles from which thin single-chunk convs use the
  *   persistent software-pipelined kernel instead of the one-tile-per-block kernel.
  *   "thin8_min_tiles" (default 2048): number of pixel tiles from which 8-output-channel convs run on the VALU
