@@ -861,6 +861,12 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
             bofs[nt][g] = P * PIXB + ((oq ^ ((P >> SWS) & (OCT - 1))) * 16);
         }
 
+    // output / mask-input element offsets of this lane's 4 pixel groups relative to the tile origin (32-bit; the tile
+    // origin is a wave-uniform 64-bit base: no per-lane 64-bit multiplies in the tile loop)
+    int ooff[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) ooff[nt] = ((2 * wave + (nt >> 1)) * A.Wo + 16 * (nt & 1) + px) * A.Mout + (m4 < A.Mout ? m4 : 0);
+
     float s1[ACC] = {0.f, 0.f, 0.f, 0.f}, s2[ACC] = {0.f, 0.f, 0.f, 0.f};
     TileWalk<TH, TW> walk;
     walk.init(A.tiles, A.tiles_x, A.total_tiles);
@@ -885,16 +891,17 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
         const TileOrg nx2 = tl + 2 * walk.step < walk.tlend ? walk.next(nxt) : nxt;
         const TileOrg nx3 = tl + 3 * walk.step < walk.tlend ? walk.next(nx2) : nx2;
         const int b = cur.b, y0 = cur.ty * TH, x0 = cur.tx * TW;
+        const size_t tbase = (((size_t)b * A.Ho + y0) * A.Wo + x0) * A.Mout;       // wave-uniform element offset of the tile
+        bool pvalid[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+            pvalid[nt] = y0 + 2 * wave + (nt >> 1) < A.Ho && x0 + 16 * (nt & 1) + px < A.Wo && m4 < A.Mout;
         // producer's z for the epilogue mask: requested now, consumed after the MFMAs
         typename Raw4<AT>::type zq[EPI == EPI_MASK ? NTW : 1];
         if constexpr (EPI == EPI_MASK) {
+            const AT* zb = reinterpret_cast<const AT*>(A.zin) + tbase;
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                int y = y0 + 2 * wave + (nt >> 1), x = x0 + 16 * (nt & 1) + px;
-                y = y < A.Ho ? y : A.Ho - 1; x = x < A.Wo ? x : A.Wo - 1;
-                const int mm = m4 < A.Mout ? m4 : 0;
-                zq[nt] = ldraw4<AT>(reinterpret_cast<const AT*>(A.zin) + (((size_t)b * A.Ho + y) * A.Wo + x) * A.Mout + mm);
-            }
+            for (int nt = 0; nt < NTW; ++nt) zq[nt] = ldraw4<AT>(zb + (pvalid[nt] ? ooff[nt] : 0));   // (tile origin is in range)
         }
         store(nxt, buf ^ 1, R0);                                // (a dummy repeat behind the last tile: branch-free body)
         if constexpr (DEEP) { R0 = R1; load(nx3, R1); }
@@ -943,9 +950,7 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
         // ---- epilogue of this tile: lane holds channels m4..m4+3 of pixel (row 2 wave + nt/2, x = 16 (nt&1) + px) ----
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const int y = y0 + 2 * wave + (nt >> 1), x = x0 + 16 * (nt & 1) + px;
-            const bool valid = y < A.Ho && x < A.Wo && m4 < A.Mout;
-            const size_t pix = ((size_t)b * A.Ho + (y < A.Ho ? y : 0)) * A.Wo + (x < A.Wo ? x : 0);
+            const bool valid = pvalid[nt];
             float v[4] = {acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]};
             if constexpr (EPI == EPI_FWD) {
                 v[0] += bias.x; v[1] += bias.y; v[2] += bias.z; v[3] += bias.w;
@@ -963,13 +968,13 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
                 for (int k = 0; k < 4; ++k) {
                     const float yv = fmaf(ka[k], zz[k], kb[k]);
                     float gv = v[k];
-                    if (A.drop_out) gv *= drop_mul(A.drop, (uint32_t)(pix * A.Mout + (valid ? m4 + k : 0)));
+                    if (A.drop_out) gv *= drop_mul(A.drop, (uint32_t)tbase + (uint32_t)(valid ? ooff[nt] + k : 0));
                     gv = (valid && yv > 0.f) ? gv : 0.f;
                     const float xh = (zz[k] - km[k]) * kr[k];
                     v[k] = gv; s1[k] += gv; s2[k] += gv * xh;
                 }
             }
-            if (valid) sta4<AT>(reinterpret_cast<AT*>(A.out) + pix * A.Mout + m4, make_float4(v[0], v[1], v[2], v[3]));
+            if (valid) sta4<AT>(reinterpret_cast<AT*>(A.out) + tbase + ooff[nt], make_float4(v[0], v[1], v[2], v[3]));
         }
         cur = nxt;
         __syncthreads();

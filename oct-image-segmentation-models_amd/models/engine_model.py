@@ -249,9 +249,29 @@ class Model:
             lab = (np.argmax(y, axis=-1) if (y.ndim == 4 and y.shape[-1] > 1) else y.reshape(y.shape[:3])).astype(np.uint8)
         lo, hi = parallel.shard_batch(X.shape[0], rank, world)
         dev = self._engine.device if self._engine is not None else self._dev()
-        x = torch.from_numpy(np.ascontiguousarray(X[lo:hi])).to(dev, non_blocking=True)
-        l = torch.from_numpy(np.ascontiguousarray(lab[lo:hi])).to(dev, non_blocking=True)
+        # pinned, double-buffered staging: a pageable source makes `non_blocking=True` a synchronous copy; with two pinned
+        # buffers per tensor the upload of batch i+1 can be queued while the step of batch i is still running
+        slot = self._stage_slot = 1 - getattr(self, "_stage_slot", 1)
+        evs = self.__dict__.setdefault("_stage_events", {})
+        if slot in evs:
+            evs[slot].synchronize()          # the copies that last read this slot's pinned buffers have executed
+        x = self._staged(("x", slot), X[lo:hi]).to(dev, non_blocking=True)
+        l = self._staged(("l", slot), lab[lo:hi]).to(dev, non_blocking=True)
+        if dev.type == "cuda":
+            evs[slot] = torch.cuda.Event(); evs[slot].record(torch.cuda.current_stream(dev))
         return x, l
+
+    def _staged(self, key, arr: np.ndarray) -> torch.Tensor:
+        arr = np.ascontiguousarray(arr)
+        pool = self.__dict__.setdefault("_pinned", {})
+        buf = pool.get(key)
+        if buf is None or buf.shape != arr.shape or buf.numpy().dtype != arr.dtype:
+            buf = torch.from_numpy(np.empty_like(arr))
+            if torch.cuda.is_available():
+                buf = buf.pin_memory()
+            pool[key] = buf
+        buf.numpy()[...] = arr
+        return buf
 
     def _run_epoch(self, seq, training: bool, rank: int, world: int):
         focal = getattr(self, "_focal", None)

@@ -1,6 +1,10 @@
 #!/bin/bash
-# sweep launch-geometry options; prints scans/s per setting
-for o in "" "dw32_blocks=384" "dw32_blocks=768" "dw32_blocks=1024" "dw16_blocks=512" "dw16_blocks=1024" "dw16_blocks=1536" "igemm_persistent_blocks=1024" "igemm_persistent_blocks=1536" "igemm_persistent_blocks=2048" "igemm_min_blocks=256" "igemm_min_blocks=768" "igemm_min_blocks=1024"; do
-  v=$(OCT_OPTIONS=$o python bench.py --no-cpu-baseline --no-profile --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['inference_ms_per_scan'])")
-  echo "[$o] $v"
+# Runs on the GPU box: bench.py (train steps only) under a list of OCT_OPTIONS settings, one line each.
+# Usage: tools/sweep_options.sh "name=v,name=v" "name=v" ...
+set -uo pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+for O in "default" "$@"; do
+  if [ "$O" = "default" ]; then unset OCT_OPTIONS; else export OCT_OPTIONS="$O"; fi
+  R=$(timeout -k 10 120 python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile --no-inference 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['step_ms_median_events'])") || R="failed"
+  echo "$O : $R"
 done
