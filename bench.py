@@ -140,8 +140,10 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def latest_pmc_file():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+def latest_pmc_file(cfg_label):
+    """The committed rocprofv3 --pmc summary of the newest round for this BASELINE configuration (None otherwise)."""
+    pat = {"configs[1]": "r[0-9][0-9]_pmc_traffic.json", "configs[2]": "r[0-9][0-9]_cfgC_pmc_traffic.json"}.get(cfg_label)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat))) if pat else []
     return files[-1] if files else None
 
 
@@ -312,9 +314,9 @@ def main():
         worst_name, worst = min(inst.items(), key=lambda kv: roof_of(kv[1])["frac"])
         # HBM traffic from the committed rocprofv3 --pmc passes of this same command (never measured by this run)
         traffic = traffic_ratio = step_traffic = None
-        pmc_file = latest_pmc_file()
+        pmc_file = latest_pmc_file(cfg_label)
         src = None
-        if pmc_file and cfg_label == "configs[1]":
+        if pmc_file:
             try:
                 pmc = json.load(open(pmc_file))
                 src = f"{os.path.relpath(pmc_file, ROOT)} (kernels as of commit {pmc.get('commit', 'unknown')}; " \
