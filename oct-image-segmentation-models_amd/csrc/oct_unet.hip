@@ -505,7 +505,8 @@ int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, do
     if (g_mfma_mode && a.wbt && a.Mout <= 16 && a.Mout % 4 == 0 && bt_k_ok(a.Cin) && !(a.flags & F_DROP) && octets_ok &&
         (AMODE != A_DOWN2 || a.Cin == 8))
         return launch_bt<KH, AMODE, EPI>(a, B, s, layer, flops, bytes, rows);
-    if (g_mfma_mode && a.wbx && a.Mout % 32 == 0 && a.Cin % 8 == 0 && a.m_off % bx_mb(a.Mout) == 0 && octets_ok)
+    if (g_mfma_mode && a.wbx && a.Mout % 32 == 0 && a.Cin % 8 == 0 && a.m_off % bx_mb(a.Mout) == 0 && octets_ok &&
+        a.Cin <= (AMODE == A_DOWN2 ? 256 : 512))       // the kernel caches the affine rows of its K channels in LDS
         return launch_bx<KH, AMODE, EPI>(a, B, s, layer, flops, bytes, rows);
     auto blocks = [&](int th, int mb) { return (long)B * cdiv(a.Ho, th) * cdiv(a.Wo, 32) * cdiv(a.Mout, mb); };
     if constexpr (AMODE == A_NORMAL && KH == 3) {
