@@ -30,6 +30,7 @@ int g_igemm_min_blocks = 512;     // a layer takes the taller pixel tile only if
 int g_dwpair8 = 1;                // 3x3 layers with 8 output channels: pixel-pair backward-weights kernel (0 = padded 16-column kernel)
 int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
+int g_dw_side_stream = 1;          // backward-weights kernels on the handle's side stream beside the backward-data chain
 int g_bx_waves = 8;                // waves per block of conv_bx_k where the tile has >= 8 rows: 8 = two per SIMD, 4 = one per SIMD
 int g_dwbt_f32_all = 0;            // 1: fp32 mode also takes conv_dwbt_k for every thin shape (tests exercise all instantiations)
 int g_bt_blocks_per_cu = 0;        // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows: 3 / 2 / 1 at 8 / 16 / 32 input channels)
@@ -256,6 +257,9 @@ struct oct_unet {
     const void* last_x = nullptr; int last_u8 = 0;   // input of the last forward (first layer's dW re-reads it)
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     hipEvent_t tail_event = nullptr;       // recorded in backward once the decoder + bottleneck gradients are final
+    // backward-weights kernels run on an internal low-priority side stream beside the backward-data chain (they are off
+    // the critical path: dz_L -> dW_L feeds nothing until the slab reduce): fork / join with events, created with the handle
+    hipStream_t side = nullptr; std::vector<hipEvent_t> fork_ev; hipEvent_t join_ev = nullptr, prep_ev = nullptr;
     Profiler prof;
 };
 
@@ -652,16 +656,22 @@ int dice_n(int C) { return 5 * C <= 16 ? 16 : (5 * C <= 32 ? 32 : 64); }
 int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, const oct_unet_io* io, hipStream_t s) {
     Plan& pl = h->plan;
     const int nl = (int)pl.L.size();
-    if (g_mfma_mode && h->n_wbx_f) {   // this step's weights, split / rounded into bf16 MFMA operand order (one launch)
-        ProfScope ps(s, "prep_wbx_k", "all", 0, (double)h->wbx_f_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
-        prep_wbx_k<<<std::min<unsigned>((h->wbx_f_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wbx_descs, h->n_wbx_f, h->wbx_f_total);
+    // this step's weights, split / rounded into bf16 MFMA operand order (one launch per kernel family).  In a training
+    // step they run on the side stream under the first layer (which does not use them).
+    const bool fside = training && g_dw_side_stream && h->side && !(t_prof && t_prof->on);
+    hipStream_t ps_ = fside ? h->side : s;
+    if (fside) { HIP_OK(hipEventRecord(h->fork_ev[0], s)); HIP_OK(hipStreamWaitEvent(h->side, h->fork_ev[0], 0)); }
+    if (g_mfma_mode && h->n_wbx_f) {
+        ProfScope ps(ps_, "prep_wbx_k", "all", 0, (double)h->wbx_f_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
+        prep_wbx_k<<<std::min<unsigned>((h->wbx_f_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, ps_>>>(h->wbx_descs, h->n_wbx_f, h->wbx_f_total);
         HIP_OK(hipGetLastError());
     }
     if (g_mfma_mode && h->n_wbt_f) {
-        ProfScope ps(s, "prep_wbt_k", "all", 0, (double)h->wbt_f_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
-        prep_wbt_k<<<std::min<unsigned>((h->wbt_f_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wbt_descs, h->n_wbt_f, h->wbt_f_total);
+        ProfScope ps(ps_, "prep_wbt_k", "all", 0, (double)h->wbt_f_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
+        prep_wbt_k<<<std::min<unsigned>((h->wbt_f_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, ps_>>>(h->wbt_descs, h->n_wbt_f, h->wbt_f_total);
         HIP_OK(hipGetLastError());
     }
+    if (fside) HIP_OK(hipEventRecord(h->prep_ev, h->side));
     if (!training) {  // (a, b) of every block from the moving statistics: one launch
         ProfScope ps(s, "bn_infer_all_k", "all", 0, (double)pl.n_state * 4 * 3);
         BnInferAll ia{};
@@ -685,9 +695,11 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
             AT_DISPATCH(bf, pool_fwd_k<AT><<<grid, kBlock, 0, s>>>((const AT*)p.z, p.bn, (AT*)h->pooled[l.level - 1], B, p.H, p.W, p.cout));
             HIP_OK(hipGetLastError());
         }
+        if (fside && li == 1) HIP_OK(hipStreamWaitEvent(s, h->prep_ev, 0));     // first layer that reads the split weights
         const int rc = conv_forward(h, li, x, x_is_u8, B, training, s);
         if (rc) return rc;
     }
+    if (fside && nl - 1 <= 1) HIP_OK(hipStreamWaitEvent(s, h->prep_ev, 0));
     // head
     const Layer& hd = pl.L[nl - 1]; const Layer& last = pl.L[nl - 2];
     HeadFwdArgs a{};
@@ -851,24 +863,33 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     hb.labels = labels; hb.bc = h->dice_bc; hb.g = last.g; hb.part = h->stat_part; hb.wpart = hd.dwp;
     hb.HW = hd.H * hd.W; hb.nblk = head_nblk(hb.HW, B); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale; hb.act_bf16 = h->cfg.dtype;
     hb.focal_w = h->focal_w; hb.focal_gamma = h->focal_gamma; hb.focal_cw = h->focal_cw; hb.focal_clip_mod = g_focal_clip_mod; hb.inv_count = 1.f / ((float)B * hb.HW);
-    {   // backward-data weights of every block for this step's parameters (one launch)
-        ProfScope ps(s, "prep_wt_k", "all", 0, (double)h->wt_total * 8);
-        prep_wt_k<<<std::min<unsigned>((h->wt_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wt_descs, h->n_wt, h->wt_total);
+    // backward-data weights of every block for this step's parameters: transposed / effective fp32 kernels, then their
+    // bf16 operand layouts.  Nothing needs them before the first backward-data launch, so they run on the side stream
+    // under the head backward and the last block's BN backward.
+    const bool side_ok = g_dw_side_stream && h->side && !(t_prof && t_prof->on);
+    hipStream_t ps_ = side_ok ? h->side : s;
+    if (side_ok) { HIP_OK(hipEventRecord(h->fork_ev[0], s)); HIP_OK(hipStreamWaitEvent(h->side, h->fork_ev[0], 0)); }
+    {
+        ProfScope ps(ps_, "prep_wt_k", "all", 0, (double)h->wt_total * 8);
+        prep_wt_k<<<std::min<unsigned>((h->wt_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, ps_>>>(h->wt_descs, h->n_wt, h->wt_total);
         HIP_OK(hipGetLastError());
     }
     if (g_mfma_mode && h->n_wbx_b) {
-        ProfScope ps(s, "prep_wbx_k", "all", 0, (double)h->wbx_b_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
-        prep_wbx_k<<<std::min<unsigned>((h->wbx_b_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wbx_descs + h->n_wbx_f, h->n_wbx_b, h->wbx_b_total);
+        ProfScope ps(ps_, "prep_wbx_k", "all", 0, (double)h->wbx_b_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
+        prep_wbx_k<<<std::min<unsigned>((h->wbx_b_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, ps_>>>(h->wbx_descs + h->n_wbx_f, h->n_wbx_b, h->wbx_b_total);
         HIP_OK(hipGetLastError());
     }
     if (g_mfma_mode && h->n_wbt_b) {
-        ProfScope ps(s, "prep_wbt_k", "all", 0, (double)h->wbt_b_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
-        prep_wbt_k<<<std::min<unsigned>((h->wbt_b_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, s>>>(h->wbt_descs + h->n_wbt_f, h->n_wbt_b, h->wbt_b_total);
+        ProfScope ps(ps_, "prep_wbt_k", "all", 0, (double)h->wbt_b_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
+        prep_wbt_k<<<std::min<unsigned>((h->wbt_b_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, ps_>>>(h->wbt_descs + h->n_wbt_f, h->n_wbt_b, h->wbt_b_total);
         HIP_OK(hipGetLastError());
     }
+    if (side_ok) HIP_OK(hipEventRecord(h->prep_ev, h->side));
+    bool prep_pending = side_ok;
     int rc = DISPATCH_C(launch_head_bwd, h->cfg.n_cls, hb, hd.cin, B, s);
     if (rc) return rc;
     int pending_nblk = B * hb.nblk;           // number of stat partial rows waiting for block (li-1)
+    bool forked = false;
     h->red.n = 0;
     queue_reduce(h, hd, pending_nblk);   // head kernel/bias gradient rows written by head_bwd_k
 
@@ -877,9 +898,19 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         // g buffer of block li is complete (+ partials in stat_part) -> dz in place
         rc = bn_backward(h, li, pending_nblk, B, s);
         if (rc) return rc;
-        rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s);
+        const bool fork = side_ok;     // (the per-launch profiler wants serial launches)
+        if (fork) {
+            hipEvent_t e = h->fork_ev[1 + li % (h->fork_ev.size() - 1)];
+            HIP_OK(hipEventRecord(e, s));                        // dz of block li is final here
+            HIP_OK(hipStreamWaitEvent(h->side, e, 0));
+            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, h->side);
+            forked = true;
+        } else {
+            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s);
+        }
         if (rc) return rc;
         if (h->tail_event && li == first_mid_layer(pl)) {
+            if (forked) { HIP_OK(hipEventRecord(h->join_ev, h->side)); HIP_OK(hipStreamWaitEvent(s, h->join_ev, 0)); }
             // every parameter gradient at offsets >= L[li].w_off (bottleneck, decoder, head: Keras creation order) is
             // final once the queued slabs are summed: the DP launcher all-reduces that segment on a side stream while
             // the encoder backward runs
@@ -888,6 +919,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             HIP_OK(hipEventRecord(h->tail_event, s));
         }
         if (l.src == SRC_INPUT) break;
+        if (prep_pending) { HIP_OK(hipStreamWaitEvent(s, h->prep_ev, 0)); prep_pending = false; }   // first backward-data launch
         // backward-data through the MFMA implicit-GEMM kernel: dz (plain) x transposed / effective weights
         int rows = 0;
         auto dx = [&](void* gout, int Cg, int ci_off, const Layer* prod, bool up) -> int {
@@ -964,6 +996,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         }
         if (rc) return rc;
     }
+    if (forked) { HIP_OK(hipEventRecord(h->join_ev, h->side)); HIP_OK(hipStreamWaitEvent(s, h->join_ev, 0)); }
     return flush_reduce(h, s);
 }
 
@@ -1097,12 +1130,31 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_u8_lut), lut, sizeof lut);
     if (e != hipSuccess) { delete h; return fail(-5, std::string("hipMemcpyToSymbol: ") + hipGetErrorString(e)); }
+    if (c->training) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // lo = numerically largest = least urgent
+        if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) h->side = nullptr;
+        if (h->side) {
+            h->fork_ev.resize(9);
+            bool ok = hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&h->prep_ev, hipEventDisableTiming) == hipSuccess;
+            for (auto& e : h->fork_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
+        }
+    }
     *out = h;
     return 0;
 }
 
 void oct_unet_destroy(oct_unet* h) {
     if (!h) return;
+    if (h->side) {
+        (void)hipStreamSynchronize(h->side);
+        for (auto e : h->fork_ev) if (e) (void)hipEventDestroy(e);
+        if (h->join_ev) (void)hipEventDestroy(h->join_ev);
+        if (h->prep_ev) (void)hipEventDestroy(h->prep_ev);
+        (void)hipStreamDestroy(h->side);
+    }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     delete h;
@@ -1279,7 +1331,7 @@ const Opt k_opts[] = {
     {"dw16_blocks", &g_dw16_blocks, 64}, {"igemm_persistent_blocks", &g_igemm_p_blocks, 8},
     {"igemm_min_blocks", &g_igemm_min_blocks, 1}, {"dwpair8_enable", &g_dwpair8, 0},
     {"pair8_geometry", &g_pair_geo, 111}, {"pair8_min_tiles", &g_pair_min_tiles, 1}, {"thin8_min_tiles", &g_thin_min_tiles, 1},
-    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0}, {"dwbt_f32_all", &g_dwbt_f32_all, 0}, {"bx_waves", &g_bx_waves, 4},
+    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0}, {"dwbt_f32_all", &g_dwbt_f32_all, 0}, {"bx_waves", &g_bx_waves, 4}, {"dw_side_stream", &g_dw_side_stream, 0},
 };
 }  // namespace
 
@@ -1306,6 +1358,7 @@ int oct_set_option(const char* name, int value) {
     if (!strcmp(name, "dwbx_blocks")) { g_dwbx_blocks = value < 8 ? 8 : value; return 0; }
     if (!strcmp(name, "bt_blocks_per_cu")) { g_bt_blocks_per_cu = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "dwbt_f32_all")) { g_dwbt_f32_all = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "dw_side_stream")) { g_dw_side_stream = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bx_waves")) { if (value != 4 && value != 8) return fail(-1, "bx_waves must be 4 or 8"); g_bx_waves = value; return 0; }
     return fail(-1, std::string("unknown option: ") + name);
 }
