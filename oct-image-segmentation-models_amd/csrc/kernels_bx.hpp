@@ -873,7 +873,7 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
     // Global loads run one tile ahead in registers.  (Two tiles ahead -- DEEP -- was measured: the second register set
     // costs a resident block per CU at 8 channels and pushes the 16-channel mask epilogue past its register budget:
     // 1.33 -> 1.49 ms over the thin layers of a step.)
-    constexpr bool DEEP = false;
+    constexpr bool DEEP = false;                             // (also measured for bf16 storage, where a set is half the size: 5.16 -> 5.35 ms at cfg-C)
     RegSet R0, R1;
     TileOrg cur = walk.first(A.tiles);
     if (walk.tl0 < walk.tlend) {
