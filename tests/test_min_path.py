@@ -73,3 +73,31 @@ def test_clean_maps_reproduce_truth_boundaries(gs):
     maps = cu.convert_predictions_to_maps_semantic(cu.labels_to_categorical(lab, C))[0]
     preds, errors, _ = gs.segment_maps(np.transpose(maps, (0, 2, 1)), truths, gs.create_graph_structure((W, H)))
     assert np.array_equal(preds, truths) and np.all(errors == 0)
+
+
+def test_segment_pool_equals_inline_segment_maps():
+    """min_path_processing/pool.py (BASELINE configs[4] host stage): spawned workers return exactly what
+    graph_search.segment_maps returns inline, in input order, with and without ground-truth boundaries."""
+    from oct_image_segmentation_models_amd.min_path_processing import graph_search
+    from oct_image_segmentation_models_amd.min_path_processing.pool import SegmentPool
+    n, H, W = 5, 48, 96
+    maps = np.zeros((n, 2, H, W), np.uint8)
+    truths = np.zeros((n, 2, W))
+    for i in range(n):
+        for c in range(2):
+            rows = (H * (c + 1) // 3 + 3 * np.sin(np.arange(W) / 7.0 + i)).astype(int)
+            maps[i, c, rows, np.arange(W)] = 255
+            maps[i, c, (rows + 5) % H, np.arange(W)] = 90            # a weaker competing ridge
+            truths[i, c] = rows
+    grid = graph_search.create_graph_structure((W, H), 1)
+    want = [graph_search.segment_maps(np.transpose(maps[i], (0, 2, 1)), truths[i], grid)[:2] for i in range(n)]
+    with SegmentPool((H, W), 1, workers=2) as pool:
+        got = pool.segment(maps, truths)
+        got_async = pool.segment_async(maps[:2]).get()
+    with SegmentPool((H, W), 1, workers=1) as solo:
+        got1 = solo.segment(maps, truths)
+    for i in range(n):
+        for g in (got, got1):
+            assert np.array_equal(g[i][0], want[i][0]) and np.array_equal(g[i][1], want[i][1], equal_nan=True)
+        assert np.array_equal(want[i][0][0], truths[i, 0].astype(np.uint16))   # the bright ridge is found
+    assert np.array_equal(got_async[1][0], want[1][0])
