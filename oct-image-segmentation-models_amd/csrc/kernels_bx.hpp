@@ -700,6 +700,7 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
 struct WbtDesc {
     const float* src; bf16_t* dst;
     int KH, Kc, M, ld, m_off, CT, NS;    // src[(tap * Kc + c) * ld + m]; rows m_off .. m_off + 15
+    int m2;                              // 8-row slice in the two-pixel form (see conv_bt_k M2): row = dx * 8 + channel
     unsigned start, count;               // work items: (K-group, row, K-slice)
 };
 
@@ -714,8 +715,15 @@ __global__ __launch_bounds__(kBlock) void prep_wbt_k(const WbtDesc* __restrict__
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k32 = kg * 8 + j, tap = g * tpm + k32 / D.CT, c = k32 % D.CT, mg = D.m_off + m;
-            v[j] = (tap < taps && c < D.Kc && mg < D.M) ? D.src[((size_t)tap * D.Kc + c) * D.ld + mg] : 0.f;
+            const int k32 = kg * 8 + j, c = k32 % D.CT;
+            int tap = g * tpm + k32 / D.CT, mg = D.m_off + m;
+            bool ok = tap < taps;
+            if (D.m2) {     // K runs over the (KH) x (KH + 1) window two adjacent output pixels share; row (dx, channel)
+                const int e = tap, ky = e / (D.KH + 1), kx = e % (D.KH + 1) - (m >> 3);
+                ok = e < D.KH * (D.KH + 1) && kx >= 0 && kx < D.KH;
+                tap = ky * D.KH + kx; mg = D.m_off + (m & 7);
+            }
+            v[j] = (ok && c < D.Kc && mg < D.M) ? D.src[((size_t)tap * D.Kc + c) * D.ld + mg] : 0.f;
         }
         bf16_t* base = D.dst + ((size_t)g * D.NS * 16 + m) * 32 + kg * 8;
         if (D.NS == 3) {
@@ -728,18 +736,31 @@ __global__ __launch_bounds__(kBlock) void prep_wbt_k(const WbtDesc* __restrict__
         }
     }
 }
-__host__ inline int wbt_groups(int KH, int CT) { const int tpm = 32 / CT; return (KH * KH + tpm - 1) / tpm; }
-__host__ inline size_t wbt_bytes(int KH, int CT, int NS) { return (size_t)wbt_groups(KH, CT) * NS * 16 * 32 * 2; }
+__host__ inline int wbt_groups(int KH, int CT, bool m2 = false) { const int tpm = 32 / CT; return (KH * (m2 ? KH + 1 : KH) + tpm - 1) / tpm; }
+__host__ inline size_t wbt_bytes(int KH, int CT, int NS, bool m2 = false) { return (size_t)wbt_groups(KH, CT, m2) * NS * 16 * 32 * 2; }
 
-template <int KH, int AMODE, int EPI, int CT, int NS, typename AT>
+template <int KH, int AMODE, int EPI, int CT, int NS, typename AT, bool M2 = false>
 __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void conv_bt_k(const IgemmArgs A) {
-    constexpr int TH = 8, TW = 32, TAPS = KH * KH, TPM = 32 / CT, NG = (TAPS + TPM - 1) / TPM, OCT = CT / 8;
-    constexpr int NTW = 4, ACC = 4, MB = 16;
+    static_assert(!M2 || ((CT == 8 || CT == 16) && AMODE != A_DOWN2), "two-pixel form: 8 or 16 K channels, unit-stride or upsampled input");
+    constexpr int TH = 8, TW = 32, TAPS = KH * (M2 ? KH + 1 : KH), TPM = 32 / CT, NG = (TAPS + TPM - 1) / TPM, OCT = CT / 8;
+    constexpr int KW = M2 ? KH + 1 : KH;                          // taps per kernel row of the (extended) window
+    constexpr int NTW = M2 ? 2 : 4, ACC = 4, MB = 16;
+    constexpr bool SW2 = M2 && AMODE == A_NORMAL;                // fragments read every second pixel: two-bit swizzle
     constexpr int IH = AMODE == A_NORMAL ? TH + KH - 1 : (AMODE == A_UPF ? TH / 2 + 1 : 2 * TH + 1);
     constexpr int IW = AMODE == A_NORMAL ? TW + KH - 1 : (AMODE == A_UPF ? TW / 2 + 1 : 2 * TW + 1);
     constexpr int NPIX = IH * IW, PPS = kBlock / OCT, NSLOT = (NPIX + PPS - 1) / PPS, NPIXP = NSLOT * PPS;
     constexpr int PIXB = CT * 2, PLANE_B = NPIXP * PIXB, IN_B = NS * PLANE_B;
     constexpr int SWS = OCT == 4 ? 2 : 3;                       // swizzle: octet ^= (pixel >> SWS) & (OCT - 1)
+    // byte offset of octet o of pixel P inside a term's image.  Unit-stride readers (16 lanes = 16 consecutive pixels)
+    // need the octet folded with a pixel bit; the two-pixel form reads pixels 2n + const: with Q = P >> 1 the 16-byte
+    // chunk index must be a bijection of Q mod 16 -> pixel parity ^= bit 4 (8 channels), parity ^= bit 3 and octet ^=
+    // bit 4 (16 channels).
+    auto lds_off = [](int P, int o) {
+        if constexpr (SW2) {
+            if constexpr (OCT == 1) return (P ^ ((P >> 4) & 1)) * PIXB;
+            else return (P ^ ((P >> 3) & 1)) * PIXB + ((o ^ ((P >> 4) & 1)) * 16);
+        } else return P * PIXB + ((o ^ ((P >> SWS) & (OCT - 1))) * 16);
+    };
     __shared__ __attribute__((aligned(256))) char smem[2 * IN_B + (4 * MB + 4 * 2 * MB) * 4];
     float* const epi = reinterpret_cast<float*>(smem + 2 * IN_B);     // EPI_MASK: producer's BN rows a / b / mean / rstd
     float* const red = epi + 4 * MB;
@@ -762,7 +783,8 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
             epi[e] = m < A.Mout ? A.bnin[arr * A.Mout + m] : 0.f;
         }
     }
-    const int m4 = 4 * kg;                                       // this lane's output channels m4 .. m4 + 3
+    // this lane's output channels m4 .. m4 + 3; two-pixel form: rows 0-7 = pixel 2 px, rows 8-15 = pixel 2 px + 1
+    const int m4 = M2 ? 4 * (kg & 1) : 4 * kg, dx = M2 ? kg >> 1 : 0;
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EPI == EPI_FWD && m4 < A.Mout) bias = ld4(A.bias + A.m_off + m4);
 
@@ -786,7 +808,7 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
     for (int k = 0; k < NSLOT; ++k) {
         const int P = tid / OCT + k * PPS;
         sly[k] = P < NPIX ? P / IW : -1000000; slx[k] = P % IW;                 // pad pixels fall outside every image
-        sdst[k] = P * PIXB + ((o ^ ((P >> SWS) & (OCT - 1))) * 16);
+        sdst[k] = lds_off(P, o);
     }
     struct RegSet { typename Raw4<AT>::type v[NSLOT][2]; };
     auto origin = [&](const TileOrg& t, int& iy0, int& ix0) {
@@ -846,26 +868,29 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
     for (int g = 0; g < NG; ++g) {
         int tap = g * TPM + kg / OCT;
         tap = tap < TAPS ? tap : TAPS - 1;                      // absent taps carry zero weights: any valid address will do
-        tky[g] = tap / KH; tkx[g] = tap % KH;
+        tky[g] = tap / KW; tkx[g] = tap % KW;
     }
     int bofs[NTW][NG];                                          // byte offset of this lane's fragment in a term's image
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int r = 2 * wave + (nt >> 1), x = 16 * (nt & 1) + px;
+            const int r = M2 ? 2 * wave + nt : 2 * wave + (nt >> 1), x = M2 ? 2 * px : 16 * (nt & 1) + px;
             int P;
             if constexpr (AMODE == A_NORMAL) P = (r + tky[g]) * IW + x + tkx[g];
             else if constexpr (AMODE == A_UPF) P = ((r + tky[g]) >> 1) * IW + ((x + tkx[g]) >> 1);
             else P = (2 * r + tky[g]) * IW + 2 * x + tkx[g];
-            bofs[nt][g] = P * PIXB + ((oq ^ ((P >> SWS) & (OCT - 1))) * 16);
+            bofs[nt][g] = lds_off(P, oq);
         }
 
     // output / mask-input element offsets of this lane's 4 pixel groups relative to the tile origin (32-bit; the tile
     // origin is a wave-uniform 64-bit base: no per-lane 64-bit multiplies in the tile loop)
     int ooff[NTW];
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) ooff[nt] = ((2 * wave + (nt >> 1)) * A.Wo + 16 * (nt & 1) + px) * A.Mout + (m4 < A.Mout ? m4 : 0);
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int r = M2 ? 2 * wave + nt : 2 * wave + (nt >> 1), x = M2 ? 2 * px + dx : 16 * (nt & 1) + px;
+        ooff[nt] = (r * A.Wo + x) * A.Mout + (m4 < A.Mout ? m4 : 0);
+    }
 
     float s1[ACC] = {0.f, 0.f, 0.f, 0.f}, s2[ACC] = {0.f, 0.f, 0.f, 0.f};
     TileWalk<TH, TW> walk;
@@ -895,7 +920,8 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
         bool pvalid[NTW];
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-            pvalid[nt] = y0 + 2 * wave + (nt >> 1) < A.Ho && x0 + 16 * (nt & 1) + px < A.Wo && m4 < A.Mout;
+            pvalid[nt] = M2 ? (y0 + 2 * wave + nt < A.Ho && x0 + 2 * px + dx < A.Wo && m4 < A.Mout)
+                            : (y0 + 2 * wave + (nt >> 1) < A.Ho && x0 + 16 * (nt & 1) + px < A.Wo && m4 < A.Mout);
         // producer's z for the epilogue mask: requested now, consumed after the MFMAs
         typename Raw4<AT>::type zq[EPI == EPI_MASK ? NTW : 1];
         if constexpr (EPI == EPI_MASK) {
@@ -937,14 +963,15 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
             }
             // pin the schedule of this basic block (hipcc otherwise sinks every LDS read next to its use): fragments two
             // steps ahead, then the step's MFMAs with a share of the next tile's conversion VALU in their shadow
-            constexpr int NPROD = NS == 3 ? 6 : 1, VPS = NS == 3 ? 16 : 8;
+            constexpr int NPROD = NS == 3 ? 6 : 1, VPS = (NS == 3 ? 16 : 8) * (M2 ? 2 : 1);
+            constexpr int WEVERY = (M2 && CT == 8) ? 2 : 4;     // LDS writes of the next tile: spread over the steps
             __builtin_amdgcn_sched_group_barrier(0x100, STEPS > 1 ? 2 * NS : NS, 0);
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 if (st + 2 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, VPS, 0);
-                if (st % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, NS, 0);
+                if (st % WEVERY == WEVERY - 1) __builtin_amdgcn_sched_group_barrier(0x200, NS, 0);
             }
         }
         // ---- epilogue of this tile: lane holds channels m4..m4+3 of pixel (row 2 wave + nt/2, x = 16 (nt&1) + px) ----
@@ -991,8 +1018,13 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
             __syncthreads();
             if (tid < 2 * MB) {
                 const int stat = tid / MB, ml = tid % MB;
-                const float s = (red[(0 * 2 + stat) * MB + ml] + red[(1 * 2 + stat) * MB + ml]) +
-                                (red[(2 * 2 + stat) * MB + ml] + red[(3 * 2 + stat) * MB + ml]);
+                float s = (red[(0 * 2 + stat) * MB + ml] + red[(1 * 2 + stat) * MB + ml]) +
+                          (red[(2 * 2 + stat) * MB + ml] + red[(3 * 2 + stat) * MB + ml]);
+                if constexpr (M2) {     // rows 8-15 are the same channels at the odd pixels
+                    const int mh = (ml + 8) % MB;
+                    s += (red[(0 * 2 + stat) * MB + mh] + red[(1 * 2 + stat) * MB + mh]) +
+                         (red[(2 * 2 + stat) * MB + mh] + red[(3 * 2 + stat) * MB + mh]);
+                }
                 if (ml < A.Mout) A.part[(size_t)blockIdx.x * (2 * A.Mout) + (size_t)stat * A.Mout + ml] = s;
             }
         }

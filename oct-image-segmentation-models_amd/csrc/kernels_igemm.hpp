@@ -43,6 +43,7 @@ struct IgemmArgs {
     DropCfg drop;
     const void* wbx; int wbx_M;                  // bf16-pipe kernels (kernels_bx.hpp): split weights of this layer direction
                                                  // in prep_wbx_k layout, and the total M the layout was built for
+    int bt_m2;                                   // ... prepared in the two-pixel form (8 output channels x 2 adjacent pixels = 16 rows)
     const void* wbt;                             // thin bf16-pipe kernel: prep_wbt_k slice for rows m_off .. m_off + 15
 };
 

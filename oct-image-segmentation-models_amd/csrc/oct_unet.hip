@@ -32,6 +32,7 @@ int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
 int g_dw_side_stream = 1;          // backward-weights kernels on the handle's side stream beside the backward-data chain
 int g_bx_waves = 8;                // waves per block of conv_bx_k where the tile has >= 8 rows: 8 = two per SIMD, 4 = one per SIMD
+int g_bt_m2 = 1;                   // conv_bt_k: 8-output-channel launches in the two-pixel form (fixed per engine at create)
 int g_dwbt_f32_all = 0;            // 1: fp32 mode also takes conv_dwbt_k for every thin shape (tests exercise all instantiations)
 int g_bt_blocks_per_cu = 0;        // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows: 3 / 2 / 1 at 8 / 16 / 32 input channels)
 int g_dwbx_blocks = 256;           // target grid of a bf16-pipe backward-weights launch (1 block per CU: the kernel needs most of the LDS)
@@ -90,6 +91,7 @@ struct Layer {
     int dw_rows = 0;       // slabs allocated at creation: a launch never uses more (tuning options may change later)
     float* wt = nullptr;   // backward-data weights: transposed+flipped 3x3, or effective 3x3 of an up-conv (9*cin*cout)
     bf16_t* wbx_f = nullptr; bf16_t* wbx_b = nullptr;   // split weights for the bf16-pipe kernels (forward / backward-data)
+    bool bt_m2_f = false, bt_m2_b = false;                // thin kernel: this layer's forward / backward-data launches use the two-pixel form
     bf16_t* wbt_f = nullptr; bf16_t* wbt_b = nullptr;   // ... for the thin bf16-pipe kernel (16-row slices; backward: cin / Cg slices)
 };
 
@@ -188,6 +190,10 @@ inline bool bt_k_ok(int k) { return k == 8 || k == 16 || k == 32; }
 inline bool bt_fwd_ok(const Layer& l) { return l.src != SRC_INPUT && l.has_bn && l.cout <= 16 && l.cout % 4 == 0 && bt_k_ok(l.cin); }
 inline bool bt_bwd_ok(const Layer& l) { const int cg = bx_bwd_cg(l); return l.src != SRC_INPUT && l.has_bn && cg <= 16 && cg % 4 == 0 && bt_k_ok(l.cout); }
 
+// two-pixel form of the thin kernel: exactly 8 output channels per launch, 8 or 16 K channels, not the stride-2 gather
+inline bool bt_m2_fwd(const Layer& l) { return g_bt_m2 && bt_fwd_ok(l) && l.cout == 8 && (l.cin == 8 || l.cin == 16); }
+inline bool bt_m2_bwd(const Layer& l) { return g_bt_m2 && bt_bwd_ok(l) && l.src != SRC_UP && bx_bwd_cg(l) == 8 && (l.cout == 8 || l.cout == 16); }
+
 // thin backward-weights on the bf16 pipe (conv_dwbt_k): the instantiated (cin, cout) pairs
 inline bool dwbt_ok(const Layer& l) {
     if (l.src == SRC_INPUT || l.kh == 1 || !l.has_bn) return false;
@@ -280,8 +286,10 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
         const int ns = c.dtype ? 1 : 3;
         bf16_t* wf = bx_fwd_ok(l) ? (bf16_t*)take(wbx_bytes(l.kh, l.cin, l.cout, bx_mb(l.cout), ns)) : nullptr;
         bf16_t* wb = (c.training && bx_bwd_ok(l)) ? (bf16_t*)take(wbx_bytes(3, l.cout, l.cin, bx_mb(bx_bwd_cg(l)), ns)) : nullptr;
-        bf16_t* tf = bt_fwd_ok(l) ? (bf16_t*)take(wbt_bytes(l.kh, l.cin, ns)) : nullptr;
-        bf16_t* tb = (c.training && bt_bwd_ok(l)) ? (bf16_t*)take(wbt_bytes(3, l.cout, ns) * (l.cin / bx_bwd_cg(l))) : nullptr;
+        const bool m2f = bt_m2_fwd(l), m2b = bt_m2_bwd(l);
+        bf16_t* tf = bt_fwd_ok(l) ? (bf16_t*)take(wbt_bytes(l.kh, l.cin, ns, m2f)) : nullptr;
+        bf16_t* tb = (c.training && bt_bwd_ok(l)) ? (bf16_t*)take(wbt_bytes(3, l.cout, ns, m2b) * (l.cin / bx_bwd_cg(l))) : nullptr;
+        if (base) { l.bt_m2_f = m2f; l.bt_m2_b = m2b; }
         if (base) { l.z = z; l.g = g; l.bn = bn; l.wt = wt; l.wbx_f = wf; l.wbx_b = wb; l.wbt_f = tf; l.wbt_b = tb; }
         // statistic partial rows: one per pixel tile; the MFMA kernels may use tiles as small as 2 x 32 pixels
         stat_max = std::max(stat_max, B * cdiv(l.H, 2) * cdiv(l.W, kTileX) * 2 * (size_t)std::max(l.cout, l.cin));
@@ -488,16 +496,29 @@ int launch_bt(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops
     const int per_cu = a.Cin == 32 ? 1 : (a.Cin == 16 ? 2 : 3);     // what the LDS images and registers of the instantiation allow
     const int nblk = std::min(a.total_tiles, g_bt_blocks_per_cu > 0 ? 256 * std::min(g_bt_blocks_per_cu, per_cu) : 256 * per_cu);
     const int bf = a.act_bf16 ? 1 : 0;
-    char nm[64]; snprintf(nm, sizeof nm, "conv_bt_k<%d,%d,%d,%d,%d,%s>", KH, AMODE, EPI, a.Cin, bf ? 1 : 3, AT_NAME(bf));
+    const bool m2 = a.bt_m2 && a.Mout == 8 && AMODE != A_DOWN2 && (a.Cin == 8 || a.Cin == 16);
+    char nm[64]; snprintf(nm, sizeof nm, "conv_bt_k<%d,%d,%d,%d,%d,%s%s>", KH, AMODE, EPI, a.Cin, bf ? 1 : 3, AT_NAME(bf), m2 ? ",2px" : "");
     ProfScope ps(s, nm, layer, flops, bytes);
+    if (a.bt_m2 && !m2) return fail(-3, "conv_bt_k: weights were prepared in the two-pixel form for a launch that cannot use it");
 #define BT_CASE(CT) case CT: if (bf) conv_bt_k<KH, AMODE, EPI, CT, 1, bf16_t><<<nblk, kBlock, 0, s>>>(a); \
                              else conv_bt_k<KH, AMODE, EPI, CT, 3, float><<<nblk, kBlock, 0, s>>>(a); break;
+#define BT_M2(CT) case CT: if (bf) conv_bt_k<KH, AMODE, EPI, CT, 1, bf16_t, true><<<nblk, kBlock, 0, s>>>(a); \
+                           else conv_bt_k<KH, AMODE, EPI, CT, 3, float, true><<<nblk, kBlock, 0, s>>>(a); break;
+    if constexpr (AMODE != A_DOWN2) {
+        if (m2) {
+            switch (a.Cin) { BT_M2(8) BT_M2(16) default: break; }
+            HIP_OK(hipGetLastError());
+            *rows = nblk;
+            return 0;
+        }
+    }
     if constexpr (AMODE == A_DOWN2) {     // the 2x-strided input tile only fits the LDS double buffer at 8 channels
         switch (a.Cin) { BT_CASE(8) default: return fail(-3, "conv_bt_k: stride-2 gather needs 8 K channels"); }
     } else {
         switch (a.Cin) { BT_CASE(8) BT_CASE(16) BT_CASE(32) default: return fail(-3, "conv_bt_k: K channels must be 8, 16 or 32"); }
     }
 #undef BT_CASE
+#undef BT_M2
     HIP_OK(hipGetLastError());
     *rows = nblk;
     return 0;
@@ -572,7 +593,7 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
         g.Cin = l.cin; g.w = a.w; g.w_ld = l.cout; g.m_off = 0; g.bias = a.bias; g.out = l.z; g.Mout = l.cout;
         g.Ho = l.H; g.Wo = l.W; g.Hi = l.src == SRC_UP ? l.H / 2 : l.H; g.Wi = l.src == SRC_UP ? l.W / 2 : l.W;
         g.part = a.part; g.drop = a.drop; g.act_bf16 = h->cfg.dtype;
-        g.wbx = l.wbx_f; g.wbx_M = l.cout; g.wbt = l.wbt_f;
+        g.wbx = l.wbx_f; g.wbx_M = l.cout; g.wbt = l.wbt_f; g.bt_m2 = l.bt_m2_f;
         rc = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows)
                              : launch_igemm<3, A_NORMAL, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows);
     } else if (l.src == SRC_INPUT && l.cin == 1 && l.cout == 8 && l.kh == 3) {   // the real first layer: persistent streaming kernel
@@ -930,7 +951,8 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             g.part = prod ? h->stat_part : nullptr; g.zin = prod ? prod->z : nullptr; g.bnin = prod ? prod->bn : nullptr;
             g.drop_out = (up && l.drop_in) ? 1 : 0; g.drop = make_drop(h); g.act_bf16 = h->cfg.dtype;
             g.wbx = l.wbx_b; g.wbx_M = l.cin;
-            g.wbt = l.wbt_b ? l.wbt_b + (size_t)(ci_off / Cg) * (wbt_bytes(3, l.cout, h->cfg.dtype ? 1 : 3) / 2) : nullptr;
+            g.wbt = l.wbt_b ? l.wbt_b + (size_t)(ci_off / Cg) * (wbt_bytes(3, l.cout, h->cfg.dtype ? 1 : 3, l.bt_m2_b) / 2) : nullptr;
+            g.bt_m2 = l.bt_m2_b;
             const double px = (double)B * l.H * l.W, pxg = (double)B * g.Ho * g.Wo;
             const double fl = 2.0 * l.kh * l.kw * Cg * l.cout * px;          // algorithmic flops of the original conv's dX
             const int es = h->cfg.dtype ? 2 : 4;
@@ -1105,7 +1127,7 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
         for (auto& l : h->plan.L) {
             if (!l.wbt_f) continue;
             WbtDesc w{}; w.src = params + l.w_off; w.dst = l.wbt_f; w.KH = l.kh; w.Kc = l.cin; w.M = l.cout; w.ld = l.cout;
-            w.m_off = 0; w.CT = l.cin; w.NS = ns; w.start = off; w.count = (unsigned)wbt_groups(l.kh, l.cin) * 64;
+            w.m_off = 0; w.CT = l.cin; w.NS = ns; w.m2 = l.bt_m2_f; w.start = off; w.count = (unsigned)wbt_groups(l.kh, l.cin, l.bt_m2_f) * 64;
             off += w.count; d.push_back(w);
         }
         h->n_wbt_f = (int)d.size(); h->wbt_f_total = off;
@@ -1114,9 +1136,9 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
             if (!l.wbt_b) continue;
             const int cg = bx_bwd_cg(l);
             for (int sl = 0; sl < l.cin / cg; ++sl) {
-                WbtDesc w{}; w.src = l.wt; w.dst = l.wbt_b + (size_t)sl * (wbt_bytes(3, l.cout, ns) / 2); w.KH = 3; w.Kc = l.cout;
-                w.M = l.cin; w.ld = l.cin; w.m_off = sl * cg; w.CT = l.cout; w.NS = ns; w.start = off;
-                w.count = (unsigned)wbt_groups(3, l.cout) * 64;
+                WbtDesc w{}; w.src = l.wt; w.dst = l.wbt_b + (size_t)sl * (wbt_bytes(3, l.cout, ns, l.bt_m2_b) / 2); w.KH = 3; w.Kc = l.cout;
+                w.M = l.cin; w.ld = l.cin; w.m_off = sl * cg; w.CT = l.cout; w.NS = ns; w.m2 = l.bt_m2_b; w.start = off;
+                w.count = (unsigned)wbt_groups(3, l.cout, l.bt_m2_b) * 64;
                 off += w.count; d.push_back(w);
             }
         }
@@ -1331,7 +1353,7 @@ const Opt k_opts[] = {
     {"dw16_blocks", &g_dw16_blocks, 64}, {"igemm_persistent_blocks", &g_igemm_p_blocks, 8},
     {"igemm_min_blocks", &g_igemm_min_blocks, 1}, {"dwpair8_enable", &g_dwpair8, 0},
     {"pair8_geometry", &g_pair_geo, 111}, {"pair8_min_tiles", &g_pair_min_tiles, 1}, {"thin8_min_tiles", &g_thin_min_tiles, 1},
-    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0}, {"dwbt_f32_all", &g_dwbt_f32_all, 0}, {"bx_waves", &g_bx_waves, 4}, {"dw_side_stream", &g_dw_side_stream, 0},
+    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0}, {"dwbt_f32_all", &g_dwbt_f32_all, 0}, {"bt_m2", &g_bt_m2, 0}, {"bx_waves", &g_bx_waves, 4}, {"dw_side_stream", &g_dw_side_stream, 0},
 };
 }  // namespace
 
@@ -1358,6 +1380,7 @@ int oct_set_option(const char* name, int value) {
     if (!strcmp(name, "dwbx_blocks")) { g_dwbx_blocks = value < 8 ? 8 : value; return 0; }
     if (!strcmp(name, "bt_blocks_per_cu")) { g_bt_blocks_per_cu = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "dwbt_f32_all")) { g_dwbt_f32_all = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "bt_m2")) { g_bt_m2 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "dw_side_stream")) { g_dw_side_stream = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bx_waves")) { if (value != 4 && value != 8) return fail(-1, "bx_waves must be 4 or 8"); g_bx_waves = value; return 0; }
     return fail(-1, std::string("unknown option: ") + name);

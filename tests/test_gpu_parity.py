@@ -55,7 +55,7 @@ DROP_STEP = 3
 
 
 @pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111", "dw16_padded",
-                        "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all"])
+                        "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all", "bt_one_px"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant: for the thin layers the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels (otherwise only chosen on large grids); for the wide layers the
@@ -67,6 +67,7 @@ def variant(request):
     _hip.set_option("bx_waves", 4 if v == "bx_tall_w4" else 8)
     _hip.set_option("mfma_mode", 0 if v == "f32_pipe" else 1)
     _hip.set_option("dwbt_f32_all", 1 if v == "dwbt_all" else 0)     # fp32 mode: every thin dW shape on the bf16 pipe
+    _hip.set_option("bt_m2", 0 if v == "bt_one_px" else 1)           # thin kernel: 8-channel launches without the two-pixel form
     _hip.set_option("igemm_persistent_min_tiles", 1 if v == "persistent" else 1 << 30)
     _hip.set_option("thin8_min_tiles", 1 if v == "thin8_valu" or v.startswith("pair8") else 1 << 30)
     _hip.set_option("pair8_min_tiles", 1 if v.startswith("pair8") else 1 << 30)
@@ -77,6 +78,7 @@ def variant(request):
     _hip.set_option("bx_waves", 8)
     _hip.set_option("mfma_mode", 1)
     _hip.set_option("dwbt_f32_all", 0)
+    _hip.set_option("bt_m2", 1)
     _hip.set_option("dwpair8_enable", 1)
     _hip.set_option("igemm_persistent_min_tiles", 2048)
     _hip.set_option("thin8_min_tiles", 2048)
