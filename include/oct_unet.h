@@ -45,7 +45,7 @@ typedef struct oct_unet_cfg {
     int n_cls;            /* num_classes, 2..8                    (training.py:176)     */
     int H, W;             /* image_height, image_width; multiples of 2^pool_layers     */
     int max_batch;        /* largest per-rank batch any call will pass                  */
-    int start_neurons;    /* default 8; multiple of 4             (unet.py:69)          */
+    int start_neurons;    /* default 8; multiple of 4 in 4..32    (unet.py:69)          */
     int pool_layers;      /* default 4                            (unet.py:70)          */
     int conv_layers;      /* default 2                            (unet.py:71)          */
     int enc_k;            /* 3  (enc_kernel (3,3))                (unet.py:72)          */

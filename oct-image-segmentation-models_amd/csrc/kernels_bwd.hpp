@@ -235,11 +235,12 @@ struct HeadBwdArgs {
 template <int C, int CIN, typename AT>
 __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
     constexpr int NV = CIN * C + C, NG = (NV + 31) / 32;
+    constexpr int CP = CIN <= 4 ? 4 : (CIN <= 8 ? 8 : (CIN <= 16 ? 16 : 32));     // the block reduction takes powers of two
     __shared__ float red[256];
     const int b = blockIdx.y;
-    float s1[CIN], s2[CIN], wv[NG * 32];
+    float s1[CP], s2[CP], wv[NG * 32];
 #pragma unroll
-    for (int i = 0; i < CIN; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    for (int i = 0; i < CP; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
 #pragma unroll
     for (int i = 0; i < NG * 32; ++i) wv[i] = 0.f;
     float num[C], den[C];
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
     }
     const size_t row = (size_t)b * gridDim.x + blockIdx.x;
     float* out = A.part + row * (2 * CIN);
-    block_reduce_store<CIN>(s1, red, out, CIN);
-    block_reduce_store<CIN>(s2, red, out + CIN, CIN);
+    block_reduce_store<CP>(s1, red, out, CIN);
+    block_reduce_store<CP>(s2, red, out + CIN, CIN);
     float* wout = A.wpart + row * NV;
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {

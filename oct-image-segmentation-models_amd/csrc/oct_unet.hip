@@ -108,8 +108,8 @@ int check_cfg(const oct_unet_cfg* c) {
     if (c->n_cls < 2 || c->n_cls > 8) return fail(-1, "n_cls must be in 2..8");
     if (c->pool_layers < 1 || c->pool_layers > 6) return fail(-1, "pool_layers must be in 1..6");
     if (c->conv_layers < 1) return fail(-1, "conv_layers must be >= 1");
-    if (c->start_neurons != 4 && c->start_neurons != 8 && c->start_neurons != 16)
-        return fail(-1, "start_neurons must be 4, 8 or 16");
+    if (c->start_neurons < 4 || c->start_neurons > 32 || c->start_neurons % 4)
+        return fail(-1, "start_neurons must be a multiple of 4 in 4..32");
     if (c->enc_k != 3 || c->dec_k != 2) return fail(-1, "only enc_kernel (3,3) / dec_kernel (2,2) are implemented");
     const int m = 1 << c->pool_layers;
     if (c->H < m || c->W < m || c->H % m || c->W % m) return fail(-1, "H and W must be multiples of 2^pool_layers");
@@ -633,6 +633,11 @@ int launch_head_fwd(const HeadFwdArgs& a, int cin, int B, hipStream_t s) {
         case 4: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 4, AT><<<grid, block, 0, s>>>(a)); break;
         case 8: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 8, AT><<<grid, block, 0, s>>>(a)); break;
         case 16: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 16, AT><<<grid, block, 0, s>>>(a)); break;
+        case 12: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 12, AT><<<grid, block, 0, s>>>(a)); break;
+        case 20: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 20, AT><<<grid, block, 0, s>>>(a)); break;
+        case 24: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 24, AT><<<grid, block, 0, s>>>(a)); break;
+        case 28: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 28, AT><<<grid, block, 0, s>>>(a)); break;
+        case 32: AT_DISPATCH(a.act_bf16, head_fwd_k<C, 32, AT><<<grid, block, 0, s>>>(a)); break;
         default: return fail(-3, "head: unsupported start_neurons");
     }
     HIP_OK(hipGetLastError());
@@ -649,6 +654,11 @@ int launch_head_bwd(const HeadBwdArgs& a, int cin, int B, hipStream_t s) {
         case 4: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 4, AT><<<grid, block, 0, s>>>(a)); break;
         case 8: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 8, AT><<<grid, block, 0, s>>>(a)); break;
         case 16: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 16, AT><<<grid, block, 0, s>>>(a)); break;
+        case 12: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 12, AT><<<grid, block, 0, s>>>(a)); break;
+        case 20: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 20, AT><<<grid, block, 0, s>>>(a)); break;
+        case 24: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 24, AT><<<grid, block, 0, s>>>(a)); break;
+        case 28: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 28, AT><<<grid, block, 0, s>>>(a)); break;
+        case 32: AT_DISPATCH(a.act_bf16, head_bwd_k<C, 32, AT><<<grid, block, 0, s>>>(a)); break;
         default: return fail(-3, "head: unsupported start_neurons");
     }
     HIP_OK(hipGetLastError());

@@ -46,11 +46,13 @@ CASES = [
     (1, 48, 80, 3, 8, 3, 1, 3),     # ragged tiles (48x80 not multiples of the 8x32 thread tile), 3 input channels
     (1, 32, 64, 2, 16, 1, 3, 1),
     (1, 32, 64, 3, 8, 2, 2, 4),     # 4 input channels: the first layer's dW must take the image-typed (uint8 / f32) VALU path
+    (1, 32, 64, 3, 32, 1, 2, 1),    # start_neurons 32: every conv but the first on the wide kernels, 32-channel head
+    (1, 32, 64, 3, 12, 2, 2, 1),    # start_neurons 12 (12/24/48 channels): nothing divides by 8 or 32 -> the generic kernels
 ]
 # Data seeds (found offline with the oracle alone) for which every BN pre-activation of the training
 # forward stays > 2e-5 away from the ReLU kink: fp32-vs-fp64 rounding then cannot flip a ReLU mask, so the
 # gradient comparison can use tight tolerances.  The margin is re-asserted inside the test.
-MARGIN_SEED = {CASES[0]: 97, CASES[1]: 13, CASES[2]: 28, CASES[3]: 75, CASES[4]: 3}   # tools/find_margin_seed.py
+MARGIN_SEED = {CASES[0]: 97, CASES[1]: 13, CASES[2]: 28, CASES[3]: 75, CASES[4]: 3, CASES[5]: 72, CASES[6]: 58}   # tools/find_margin_seed.py
 DROP_STEP = 3
 
 
@@ -536,7 +538,8 @@ def test_config3_shape_in_its_own_dtype_bf16():
 #      unrounded oracle the gates are: probabilities 8e-2 max / 1.5e-2 mean, Dice 2e-2; gradients, which also see the
 #      ReLU masks that the forward noise flips, cosine > 0.9 per kernel tensor and > 0.97 over the whole gradient
 #      (the layer-local test above is the one that pins every backward kernel to one rounding).
-BF16_CASES = [(2, 32, 64, 3, 8, 2, 2, 1), (1, 48, 80, 3, 8, 3, 1, 3), (1, 32, 64, 3, 8, 2, 2, 4)]
+BF16_CASES = [(2, 32, 64, 3, 8, 2, 2, 1), (1, 48, 80, 3, 8, 3, 1, 3), (1, 32, 64, 3, 8, 2, 2, 4), (1, 32, 64, 3, 32, 1, 2, 1),
+              (1, 32, 64, 3, 12, 2, 2, 1)]
 
 
 def make_bf16(B, H, W, C, sn, P, L=2, in_ch=1, seed=0):
