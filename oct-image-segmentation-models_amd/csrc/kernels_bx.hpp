@@ -848,10 +848,13 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             const int gy = iy0 + sly[k], gx = ix0 + slx[k];
             const bool in = gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi;
+            // ReLU and the zero padding (applied AFTER the activation) in ONE v_med3_f32 per element: clamp to [lo, +inf)
+            // inside the image, to [0, 0] outside (two selects per pixel instead of a max and a select per element)
+            const float cl = in ? lo : 0.f, ch = in ? 3.0e38f : 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {      // zero padding is applied AFTER the activation: out-of-image stays 0
-                const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);
-                v[i] = in ? y : 0.f;
+            for (int i = 0; i < 8; i += 2) {                    // the affine as v_pk_fma_f32: two channels per instruction
+                const f32x2_hw y = __builtin_elementwise_fma(f32x2_hw{fa[i], fa[i + 1]}, f32x2_hw{v[i], v[i + 1]}, f32x2_hw{fb[i], fb[i + 1]});
+                v[i] = __builtin_amdgcn_fmed3f(y[0], cl, ch); v[i + 1] = __builtin_amdgcn_fmed3f(y[1], cl, ch);
             }
             uint4 pl[NS];
             split8<NS>(v, pl);
