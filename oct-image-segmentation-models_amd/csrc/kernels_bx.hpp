@@ -40,6 +40,18 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {      // v_cvt_pk
 __device__ __forceinline__ void touch_raw(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ void touch_raw(uint2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
 
+// consumer-side transform of 8 staged values: y = max(fa * v + fb, lo) inside the image, exactly 0 outside (zero padding
+// is applied AFTER the activation).  The affine goes as v_pk_fma_f32 (two channels per instruction), ReLU and padding as
+// ONE v_med3_f32 per element: clamp to [lo, +big) inside, to [0, 0] outside.
+__device__ __forceinline__ void act8(float (&v)[8], const float (&fa)[8], const float (&fb)[8], float lo, bool in) {
+    const float cl = in ? lo : 0.f, ch = in ? 3.0e38f : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2_hw y = __builtin_elementwise_fma(f32x2_hw{fa[i], fa[i + 1]}, f32x2_hw{v[i], v[i + 1]}, f32x2_hw{fb[i], fb[i + 1]});
+        v[i] = __builtin_amdgcn_fmed3f(y[0], cl, ch); v[i + 1] = __builtin_amdgcn_fmed3f(y[1], cl, ch);
+    }
+}
+
 // 8 floats -> NS planes of 8 bf16 (a uint4 each); planes 1 and 2 hold the exact residuals
 template <int NS>
 __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&pl)[NS]) {
@@ -237,8 +249,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
         const bool in = cok_s && goff[k] >= 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {        // zero padding is applied AFTER the activation: out-of-image stays 0
-            const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);
-            v[i] = in ? y : 0.f;
+            const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);     // (act8's med3 / pk_fma form measured slower HERE: the
+            v[i] = in ? y : 0.f;                                      //  compiler's schedule among this kernel's MFMAs changes)
         }
         if constexpr (DROP) {
             if (in) {
@@ -556,11 +568,7 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             const int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;
             const bool in = gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {      // out-of-range stays exactly zero (padding is applied after the activation)
-                const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);
-                v[i] = in ? y : 0.f;
-            }
+            act8(v, fa, fb, lo, in);
             if (A.flags & F_DROP) {            // (only the up-conv behind the bottleneck: a uniform, rarely taken branch)
                 const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
                 const uint32_t el = (uint32_t)((((size_t)b * Hs + sy) * Ws + sx) * Cs + ccx);
@@ -848,14 +856,7 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             const int gy = iy0 + sly[k], gx = ix0 + slx[k];
             const bool in = gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi;
-            // ReLU and the zero padding (applied AFTER the activation) in ONE v_med3_f32 per element: clamp to [lo, +inf)
-            // inside the image, to [0, 0] outside (two selects per pixel instead of a max and a select per element)
-            const float cl = in ? lo : 0.f, ch = in ? 3.0e38f : 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) {                    // the affine as v_pk_fma_f32: two channels per instruction
-                const f32x2_hw y = __builtin_elementwise_fma(f32x2_hw{fa[i], fa[i + 1]}, f32x2_hw{v[i], v[i + 1]}, f32x2_hw{fb[i], fb[i + 1]});
-                v[i] = __builtin_amdgcn_fmed3f(y[0], cl, ch); v[i + 1] = __builtin_amdgcn_fmed3f(y[1], cl, ch);
-            }
+            act8(v, fa, fb, lo, in);
             uint4 pl[NS];
             split8<NS>(v, pl);
             char* d = smem + buf * IN_B + sdst[k];
@@ -1128,11 +1129,7 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             const int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;
             const bool in = gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {      // out-of-range stays exactly zero (padding is applied after the activation)
-                const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);
-                v[i] = in ? y : 0.f;
-            }
+            act8(v, fa, fb, lo, in);
             if (A.flags & F_DROP) {            // (only the up-conv behind the bottleneck: a uniform, rarely taken branch)
                 const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
                 const uint32_t el = (uint32_t)((((size_t)b * Hs + sy) * Ws + sx) * Cs + ccx);
