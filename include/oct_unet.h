@@ -173,7 +173,11 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   "bx_waves" (8 | 4): waves per block of conv_bx_k where the tile has >= 8 rows (two / one per SIMD).
  *   "dwbx_blocks" (256): grid target of the wide bf16-pipe backward-weights kernel.
  *   "bt_blocks_per_cu" (0 = as many as the LDS images allow): persistent blocks of the thin bf16-pipe kernel.
+ *   "bt_m2" (1): thin bf16-pipe launches with exactly 8 output channels use the two-pixel form (16 MFMA rows = 2 adjacent
+ *   pixels x 8 channels); read when the handle is created (the weights are prepared in that form).  0 = one pixel per column.
  *   "dwbt_f32_all" (0): 1 = fp32 mode takes conv_dwbt_k for every thin backward-weights shape (default: where it wins).
+ *   "dw_side_stream" (1): backward-weights kernels and the per-step weight preparation run on a low-priority stream
+ *   owned by the handle, beside the backward-data chain.  0 = everything on the caller's stream.
  *   "igemm_persistent_min_tiles" (default 2048): number of pixel tiles from which thin single-chunk convs use the
  *   persistent software-pipelined kernel instead of the one-tile-per-block kernel.
  *   "thin8_min_tiles" (default 2048): number of pixel tiles from which 8-output-channel convs run on the VALU
