@@ -172,7 +172,7 @@ def main():
     ap.add_argument("--dump-profile", default=None, help="write the per-(kernel, layer) launch table to this JSON file")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("OCT_BENCH_REHEARSAL") != "1":
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # (the rehearsal flag travels to the ranks in the environment)
         sys.exit(spawn_ranks(args.gpus))
 
     import numpy as np
