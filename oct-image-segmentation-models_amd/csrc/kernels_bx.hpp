@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
 // ------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int KH, bool UP, int NS, typename AT>
+template <int KH, bool UP, int NS, typename AT, bool DROP = false>
 __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
     constexpr int TH = 4, TW = 32, TAPS = KH * KH;
     constexpr int IH = UP ? TH + 1 : TH + KH - 1, IW = UP ? TW + 1 : TW + KH - 1, PT = UP ? 0 : (KH - 1) / 2;
@@ -569,7 +569,8 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
             const int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;
             const bool in = gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
             act8(v, fa, fb, lo, in);
-            if (A.flags & F_DROP) {            // (only the up-conv behind the bottleneck: a uniform, rarely taken branch)
+            if constexpr (DROP) {              // (only the up-conv behind the bottleneck; compile-time: a runtime branch here
+                                               //  would cut the conversion out of the basic block that holds the MFMAs)
                 const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
                 const uint32_t el = (uint32_t)((((size_t)b * Hs + sy) * Ws + sx) * Cs + ccx);
 #pragma unroll
@@ -1048,7 +1049,7 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
 // branch-free (loads clamped, one tile ahead in registers, LDS images double buffered) so it is scheduled among the
 // MFMAs; fixed-order 4-wave sum, ONE partial slab per block.  grid (npb, 1, 1).
 // ------------------------------------------------------------------------------------------------------------------
-template <int KH, bool UP, int CI, int CO, int NS, typename AT>
+template <int KH, bool UP, int CI, int CO, int NS, typename AT, bool DROP = false>
 __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(const ConvBwdWArgs A) {
     constexpr int TH = 4, TW = 32, TAPS = KH * KH;
     constexpr int IH = UP ? TH + 1 : TH + KH - 1, IW = UP ? TW + 1 : TW + KH - 1, PT = UP ? 0 : (KH - 1) / 2;
@@ -1130,7 +1131,8 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
             const int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;
             const bool in = gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
             act8(v, fa, fb, lo, in);
-            if (A.flags & F_DROP) {            // (only the up-conv behind the bottleneck: a uniform, rarely taken branch)
+            if constexpr (DROP) {              // (only the up-conv behind the bottleneck; compile-time: a runtime branch here
+                                               //  would cut the conversion out of the basic block that holds the MFMAs)
                 const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
                 const uint32_t el = (uint32_t)((((size_t)b * Hs + sy) * Ws + sx) * Cs + ccx);
 #pragma unroll

@@ -818,20 +818,27 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
         const int bf = a.act_bf16 ? 1 : 0;
         char nm[64]; snprintf(nm, sizeof nm, "conv_dwbt_k<%d,%s,%d,%d,%d,%s>", l.kh, up ? "true" : "false", l.cin, l.cout, bf ? 1 : 3, AT_NAME(bf));
         ProfScope ps(s, nm, l.name, fl, by);
-#define DWBT(KHV, UPV, CI, CO) if (l.cin == CI && l.cout == CO) { \
-            if (bf) conv_dwbt_k<KHV, UPV, CI, CO, 1, bf16_t><<<p.npb, kBlock, 0, s>>>(a); \
-            else conv_dwbt_k<KHV, UPV, CI, CO, 3, float><<<p.npb, kBlock, 0, s>>>(a); }
+        const bool dr = (a.flags & F_DROP) != 0;          // dropout on the input: only the up-conv behind the bottleneck
+        if (dr && !up) return fail(-3, "conv_dwbt_k: dropout on the input is only built for the up-conv");
+#define DWBT_D(KHV, UPV, CI, CO, DR) { \
+            if (bf) conv_dwbt_k<KHV, UPV, CI, CO, 1, bf16_t, DR><<<p.npb, kBlock, 0, s>>>(a); \
+            else conv_dwbt_k<KHV, UPV, CI, CO, 3, float, DR><<<p.npb, kBlock, 0, s>>>(a); }
+#define DWBT(KHV, UPV, CI, CO) if (l.cin == CI && l.cout == CO) { if (UPV && dr) DWBT_D(KHV, UPV, CI, CO, UPV) else DWBT_D(KHV, UPV, CI, CO, false) }
         if (up) { DWBT(2, true, 16, 8) else DWBT(2, true, 32, 16) else return fail(-3, "conv_dwbt_k: up-conv shape not instantiated"); }
         else { DWBT(3, false, 8, 8) else DWBT(3, false, 8, 16) else DWBT(3, false, 16, 8) else DWBT(3, false, 16, 16)
                else DWBT(3, false, 16, 32) else DWBT(3, false, 32, 16) else return fail(-3, "conv_dwbt_k: shape not instantiated"); }
 #undef DWBT
+#undef DWBT_D
         HIP_OK(hipGetLastError());
     } else if (p.kind == 33) {
         dim3 grid(p.npb, l.cin / 32, l.cout / 32), block(kBlock);
         const int bf = a.act_bf16 ? 1 : 0;
         char nm[64]; snprintf(nm, sizeof nm, "conv_dwbx_k<%d,%s,%d,%s>", l.kh, up ? "true" : "false", bf ? 1 : 3, AT_NAME(bf));
         ProfScope ps(s, nm, l.name, fl, by);
-        if (up) { if (bf) conv_dwbx_k<2, true, 1, bf16_t><<<grid, block, 0, s>>>(a); else conv_dwbx_k<2, true, 3, float><<<grid, block, 0, s>>>(a); }
+        const bool dr = (a.flags & F_DROP) != 0;          // dropout on the input: only the up-conv behind the bottleneck
+        if (dr && !up) return fail(-3, "conv_dwbx_k: dropout on the input is only built for the up-conv");
+        if (up && dr) { if (bf) conv_dwbx_k<2, true, 1, bf16_t, true><<<grid, block, 0, s>>>(a); else conv_dwbx_k<2, true, 3, float, true><<<grid, block, 0, s>>>(a); }
+        else if (up) { if (bf) conv_dwbx_k<2, true, 1, bf16_t><<<grid, block, 0, s>>>(a); else conv_dwbx_k<2, true, 3, float><<<grid, block, 0, s>>>(a); }
         else { if (bf) conv_dwbx_k<3, false, 1, bf16_t><<<grid, block, 0, s>>>(a); else conv_dwbx_k<3, false, 3, float><<<grid, block, 0, s>>>(a); }
         HIP_OK(hipGetLastError());
     } else {
