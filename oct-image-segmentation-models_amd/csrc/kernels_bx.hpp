@@ -536,66 +536,75 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
         b = tl / A.tiles; const int t = tl % A.tiles;
         x0 = (t % A.tiles_x) * TW; y0 = (t / A.tiles_x) * TH;
     };
-    // Loads are UNCONDITIONAL (addresses clamped into the image; out-of-image values are discarded by store()): no
-    // exec-mask branches, so staging and the MFMA loop share one basic block and the compiler interleaves them.
-    auto load = [&](int tl, Regs& R) {
-        int b, y0, x0; tile_of(tl, b, y0, x0);
-#pragma unroll
-        for (int k = 0; k < NXS; ++k) {
-            int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;             // position in the conv-input (high-res) image
+    // Loads are UNCONDITIONAL (addresses clamped into the image; out-of-image values are discarded when stored): no
+    // exec-mask branches, so staging and the MFMA loop share one basic block.  Staging is written per ITEM (one
+    // (pixel, octet) of X or of dz per thread) so that compute() can place the items of the next tile between its steps.
+    struct Geo { int b, y0, x0; };
+    auto geo_of = [&](int tl) { Geo g; tile_of(tl, g.b, g.y0, g.x0); return g; };
+    auto load_item = [&](int i, const Geo& g, Regs& R) {
+        if (i < NXS) {
+            const int k = i;
+            int gy = g.y0 + xly[k] - PT, gx = g.x0 + xlx[k] - PT;         // position in the conv-input (high-res) image
             gy = gy < 0 ? 0 : (gy >= A.H ? A.H - 1 : gy); gx = gx < 0 ? 0 : (gx >= A.W ? A.W - 1 : gx);
             const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
-            const AT* p = xsrc + (((size_t)b * Hs + sy) * Ws + sx) * Cs;
+            const AT* p = xsrc + (((size_t)g.b * Hs + sy) * Ws + sx) * Cs;
             R.x[k][0] = ldraw4<AT>(p); R.x[k][1] = ldraw4<AT>(p + 4);
-        }
-#pragma unroll
-        for (int k = 0; k < NDS; ++k) {
+        } else {
+            const int k = i - NXS;
             const int P = (tid >> 2) + k * (kBlock / 4);
-            int py = y0 + P / TW, px = x0 + P % TW;
+            int py = g.y0 + P / TW, px = g.x0 + P % TW;
             py = py >= A.H ? A.H - 1 : py; px = px >= A.W ? A.W - 1 : px;
-            const AT* p = dsrc + (((size_t)b * A.H + py) * A.W + px) * A.Cout;
+            const AT* p = dsrc + (((size_t)g.b * A.H + py) * A.W + px) * A.Cout;
             R.d[k][0] = ldraw4<AT>(p); R.d[k][1] = ldraw4<AT>(p + 4);
         }
     };
     // `live`: false for the dummy store issued behind the last tile (keeps the loop body branch-free)
-    auto store = [&](int tl, const Regs& R, int buf, bool live) {
-        int b, y0, x0; tile_of(tl, b, y0, x0);
-        char* const Xb = smem + buf * BUF_B + o8 * 2;
-        char* const Db = smem + buf * BUF_B + NS * XPL + o8 * 2;
-#pragma unroll
-        for (int k = 0; k < NXS; ++k) {
+    auto store_item = [&](int i, const Geo& g, const Regs& R, int buf, bool live) {
+        if (i < NXS) {
+            const int k = i;
             const float4 v0 = widen4(R.x[k][0]), v1 = widen4(R.x[k][1]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;
+            const int gy = g.y0 + xly[k] - PT, gx = g.x0 + xlx[k] - PT;
             const bool in = gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
             act8(v, fa, fb, lo, in);
             if constexpr (DROP) {              // (only the up-conv behind the bottleneck; compile-time: a runtime branch here
                                                //  would cut the conversion out of the basic block that holds the MFMAs)
                 const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
-                const uint32_t el = (uint32_t)((((size_t)b * Hs + sy) * Ws + sx) * Cs + ccx);
+                const uint32_t el = (uint32_t)((((size_t)g.b * Hs + sy) * Ws + sx) * Cs + ccx);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = in ? v[i] * drop_mul(A.drop, el + i) : 0.f;
+                for (int e = 0; e < 8; ++e) v[e] = in ? v[e] * drop_mul(A.drop, el + e) : 0.f;
             }
             uint4 pl[NS];
             split8<NS>(v, pl);
             const int P = (tid >> 2) + k * (kBlock / 4);
-            char* d = Xb + P * 64;
+            char* d = smem + buf * BUF_B + o8 * 2 + P * 64;
 #pragma unroll
             for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * XPL) = pl[p];
-        }
-#pragma unroll
-        for (int k = 0; k < NDS; ++k) {
+        } else {
+            const int k = i - NXS;
             const int P = (tid >> 2) + k * (kBlock / 4);
-            const bool in = live && y0 + P / TW < A.H && x0 + P % TW < A.W;
+            const bool in = live && g.y0 + P / TW < A.H && g.x0 + P % TW < A.W;
             const float4 v0 = widen4(R.d[k][0]), v1 = widen4(R.d[k][1]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { v[i] = in ? v[i] : 0.f; bsum[i] += v[i]; }
+            for (int e = 0; e < 8; ++e) { v[e] = in ? v[e] : 0.f; bsum[e] += v[e]; }
             uint4 pl[NS];
             split8<NS>(v, pl);
+            char* d = smem + buf * BUF_B + NS * XPL + o8 * 2 + P * 64;
 #pragma unroll
-            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(Db + P * 64 + p * DPL) = pl[p];
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * DPL) = pl[p];
         }
+    };
+    constexpr int NIT = NXS + NDS;
+    auto load = [&](int tl, Regs& R) {
+        const Geo g = geo_of(tl);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) load_item(i, g, R);
+    };
+    auto store = [&](int tl, const Regs& R, int buf, bool live) {
+        const Geo g = geo_of(tl);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) store_item(i, g, R, buf, live);
     };
 
     f32x16 acc[TAPS];
@@ -612,34 +621,63 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * 64));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
-    auto compute = [&](int buf) {
+    // One flat sequence of (16-pixel K step, tap) steps.  hipcc, left alone, emits the whole conversion of the next tile
+    // first and then the MFMAs with every fragment read right in front of its use (one wave per SIMD here: nothing else
+    // covers either).  So the A fragments of step s+2 are requested before the MFMAs of step s issue (ring of 3 sets, B
+    // per K step two steps ahead of its first use) and the schedule of the block is pinned: per step the fragment reads,
+    // the step's MFMAs, a share of the next tile's conversion VALU in their shadow, a share of its LDS writes.
+    constexpr int KS = TW / 16, STEPS = KS * TAPS;
+    auto compute = [&](int buf, auto&& between) {
         const char* Xl = smem + buf * BUF_B + laneoff;
         const char* Dl = smem + buf * BUF_B + NS * XPL + laneoff + (wave * TW) * 64;
+        constexpr int DEPTH = 3;
+        bf16x8 av[DEPTH][NS], bw[2][NS];
+        auto fetch_a = [&](int st, bf16x8 (&f)[NS]) {
+            const int ks = st / TAPS, t = st % TAPS, ky = t / KH, kx = t % KH;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) f[p] = tr8(Xl + p * XPL + ((wave + ky) * IW + ks * 16 + kx) * 64);
+        };
+        auto fetch_b = [&](int ks, bf16x8 (&f)[NS]) {
+#pragma unroll
+            for (int p = 0; p < NS; ++p) f[p] = tr8(Dl + p * DPL + ks * 16 * 64);
+        };
         __builtin_amdgcn_s_setprio(1);
+        fetch_b(0, bw[0]); fetch_a(0, av[0]); fetch_a(1, av[1]);
 #pragma unroll
-        for (int ks = 0; ks < TW / 16; ++ks) {
-            bf16x8 bv[NS];
-#pragma unroll
-            for (int p = 0; p < NS; ++p) bv[p] = tr8(Dl + p * DPL + ks * 16 * 64);
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int ky = t / KH, kx = t % KH;
-                bf16x8 a[NS];
-#pragma unroll
-                for (int p = 0; p < NS; ++p) a[p] = tr8(Xl + p * XPL + ((wave + ky) * IW + ks * 16 + kx) * 64);
-                f32x16 c = acc[t];
-                if constexpr (NS == 3) {
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bv[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bv[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bv[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bv[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bv[0], c, 0, 0, 0);
-                }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bv[0], c, 0, 0, 0);
-                acc[t] = c;
+        for (int st = 0; st < STEPS; ++st) {
+            if (st + 2 < STEPS) fetch_a(st + 2, av[(st + 2) % DEPTH]);
+            if (st % TAPS == TAPS - 2 && st / TAPS + 1 < KS) fetch_b(st / TAPS + 1, bw[(st / TAPS + 1) & 1]);
+            const int t = st % TAPS;
+            const bf16x8 (&a)[NS] = av[st % DEPTH];
+            const bf16x8 (&bv)[NS] = bw[(st / TAPS) & 1];
+            f32x16 c = acc[t];
+            if constexpr (NS == 3) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bv[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bv[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bv[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bv[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bv[0], c, 0, 0, 0);
             }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bv[0], c, 0, 0, 0);
+            acc[t] = c;
+            between(st);                      // staging items of the NEXT tile, in program order behind this step's reads
         }
         __builtin_amdgcn_s_setprio(0);
+        constexpr int NPROD = NS == 3 ? 6 : 1, RPF = 2 * NS;                 // MFMAs per step; LDS reads per fragment fetch
+        constexpr int VPS = NS == 3 ? (UP ? 40 : 26) : (UP ? 24 : 14);      // conversion VALU placed under a step's MFMAs
+        constexpr int WPS = NS;                                             // LDS writes of one staging item
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * RPF, 0);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            if (st + 2 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, RPF, 0);
+            if (st % TAPS == TAPS - 2 && st / TAPS + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, RPF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPS, 0);
+            if (((st + 1) * NIT) / STEPS != (st * NIT) / STEPS) {           // a staging item ends behind this step
+                __builtin_amdgcn_sched_group_barrier(0x200, WPS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);         // and its registers are re-loaded for tile t+2
+            }
+        }
     };
 
     // ---- tile pipeline: tile t in LDS buffer `buf`, tile t+1 in registers, tile t+2 requested; per iteration ONE
@@ -655,9 +693,16 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
     int buf = 0;
     for (int tl = t0; tl < tend; tl += step, buf ^= 1) {
         const int t1 = tl + step, t2 = tl + 2 * step;
-        store(t1 < tend ? t1 : tlast, R, buf ^ 1, t1 < tend);
-        load(t2 < tend ? t2 : tlast, R);
-        compute(buf);
+        const Geo g1 = geo_of(t1 < tend ? t1 : tlast), g2 = geo_of(t2 < tend ? t2 : tlast);
+        const bool live = t1 < tend;
+        compute(buf, [&](int st) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+                if (((st + 1) * NIT) / STEPS != (st * NIT) / STEPS && (st * NIT) / STEPS == i) {
+                    store_item(i, g1, R, buf ^ 1, live);     // tile t+1: registers -> split -> LDS (other buffer)
+                    load_item(i, g2, R);                     // tile t+2: the same registers, requested right away
+                }
+        });
         __syncthreads();
     }
 
