@@ -496,9 +496,10 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
     constexpr int XPL = NPXP * 64, DPL = NPD * 64;              // bytes of one term's image (32 channels x bf16 per pixel)
     constexpr int BUF_B = NS * (XPL + DPL);
     static_assert((NPD * 4) % kBlock == 0, "dz tile items");
-    constexpr int RED_B = 4 * 16 * 64 * 4;                      // one tap's 4-wave sum
-    static_assert(2 * BUF_B >= RED_B + kBlock * 8 * 4, "scratch fits in the image buffers");
-    __shared__ __attribute__((aligned(256))) char smem[2 * BUF_B];
+    constexpr int RED_B = TAPS * 4 * 16 * 64 * 4;              // the 4-wave sum of all taps (epilogue), then the bias scratch
+    constexpr int SMEM_B = 2 * BUF_B > RED_B ? 2 * BUF_B : RED_B;
+    static_assert(SMEM_B >= 4096 * 4 + kBlock * 8 * 4, "bias scratch fits");
+    __shared__ __attribute__((aligned(256))) char smem[SMEM_B];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
@@ -706,23 +707,31 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
         __syncthreads();
     }
 
-    // ---- 4-wave sum, tap by tap, through LDS (fixed order), then the slab; bias gradient = column sums of dz ----
+    // ---- 4-wave sum of ALL taps in one pass through LDS (fixed order (w0 + w1) + (w2 + w3)), then the slab.  (Tap by tap
+    // it was 2 barriers and a round trip per tap: the fixed cost of a launch -- prologue + this epilogue -- measured as
+    // HALF of a 41 us launch.)  Image [wave][tap][register quad q][lane] of float4: 16-byte lanes, conflict-free. ----
     float* const red = reinterpret_cast<float*>(smem);
+    float4* const red4 = reinterpret_cast<float4*>(smem);
     const size_t wsize = (size_t)TAPS * A.Cin * A.Cout;
     float* out = A.part + (size_t)blockIdx.x * (wsize + A.Cout);
+    __syncthreads();                                              // every wave is done with the operand images
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-        __syncthreads();
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][r];
-        __syncthreads();
-        for (int idx = tid; idx < 16 * 64; idx += kBlock) {
-            const int r = idx / 64, ln = idx % 64;
-            const float s = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
-            const int col = ln & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-            if (ci0 + row < A.Cin && co0 + col < A.Cout)
-                out[((size_t)t * A.Cin + ci0 + row) * A.Cout + co0 + col] = s;
-        }
+        for (int q = 0; q < 4; ++q)
+            red4[((wave * TAPS + t) * 4 + q) * 64 + lane] = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {                              // thread (wave q, lane): register quad q of every tap
+        const int q = wave, e = (t * 4 + q) * 64 + lane;
+        const float4 w0 = red4[e], w1 = red4[TAPS * 256 + e], w2 = red4[2 * TAPS * 256 + e], w3 = red4[3 * TAPS * 256 + e];
+        const float sv[4] = {(w0.x + w1.x) + (w2.x + w3.x), (w0.y + w1.y) + (w2.y + w3.y),
+                             (w0.z + w1.z) + (w2.z + w3.z), (w0.w + w1.w) + (w2.w + w3.w)};
+        const int col = lane & 31, row0 = 8 * q + 4 * (lane >> 5);            // C/D layout: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr)
+            if (ci0 + row0 + jr < A.Cin && co0 + col < A.Cout)
+                out[((size_t)t * A.Cin + ci0 + row0 + jr) * A.Cout + co0 + col] = sv[jr];
     }
     __syncthreads();
     float* const bs = red + 4096;
