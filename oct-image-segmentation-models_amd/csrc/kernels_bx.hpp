@@ -885,39 +885,51 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
         const int P = tid / OCT + k * PPS, Pc = P < NPIX ? P : 0;
         soff[k] = ((Pc / IW) * A.Wi + Pc % IW) * Cs;
     }
-    auto load = [&](const TileOrg& t, RegSet& RS) {              // unconditional loads: no exec-mask branches
-        auto& R = RS.v;
+    // Staging in ITEM form (item k = pixel slot k of this thread): the address block is the only place with a branch
+    // (interior tiles: a wave-uniform tile offset + a per-item constant; border tiles: positions clamped into the image);
+    // loads are unconditional; store and load of an item are separate so that the tile loop can place them between
+    // its MFMA steps.  Offsets are 32-bit elements relative to the image of the tile's B-scan.
+    int aoff[NSLOT];
+    auto addr = [&](const TileOrg& t) -> const AT* {
         int iy0, ix0; origin(t, iy0, ix0);
-        if (iy0 >= 0 && ix0 >= 0 && iy0 + IH <= A.Hi && ix0 + IW <= A.Wi) {       // interior: wave-uniform base + constant
-            const AT* tb = xsrc + (((size_t)t.b * A.Hi + iy0) * A.Wi + ix0) * Cs;
+        if (iy0 >= 0 && ix0 >= 0 && iy0 + IH <= A.Hi && ix0 + IW <= A.Wi) {
+            const int to = (iy0 * A.Wi + ix0) * Cs;
 #pragma unroll
-            for (int k = 0; k < NSLOT; ++k) { R[k][0] = ldraw4<AT>(tb + soff[k]); R[k][1] = ldraw4<AT>(tb + soff[k] + 4); }
-        } else {                                                 // border: addresses clamped into the image
+            for (int k = 0; k < NSLOT; ++k) aoff[k] = to + soff[k];
+        } else {
 #pragma unroll
             for (int k = 0; k < NSLOT; ++k) {
                 int gy = iy0 + sly[k], gx = ix0 + slx[k];
                 gy = gy < 0 ? 0 : (gy >= A.Hi ? A.Hi - 1 : gy); gx = gx < 0 ? 0 : (gx >= A.Wi ? A.Wi - 1 : gx);
-                const AT* p = xsrc + (((size_t)t.b * A.Hi + gy) * A.Wi + gx) * Cs;
-                R[k][0] = ldraw4<AT>(p); R[k][1] = ldraw4<AT>(p + 4);
+                aoff[k] = (gy * A.Wi + gx) * Cs;
             }
         }
+        return xsrc + (size_t)(t.b * A.Hi * A.Wi) * Cs;
+    };
+    auto load_item = [&](int k, const AT* ib, RegSet& RS) {
+        RS.v[k][0] = ldraw4<AT>(ib + aoff[k]); RS.v[k][1] = ldraw4<AT>(ib + aoff[k] + 4);
+    };
+    auto store_item = [&](int k, int iy0, int ix0, int buf, const RegSet& RS) {
+        const float4 v0 = widen4(RS.v[k][0]), v1 = widen4(RS.v[k][1]);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const int gy = iy0 + sly[k], gx = ix0 + slx[k];
+        const bool in = gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi;
+        act8(v, fa, fb, lo, in);
+        uint4 pl[NS];
+        split8<NS>(v, pl);
+        char* d = smem + buf * IN_B + sdst[k];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * PLANE_B) = pl[p];
+    };
+    auto load = [&](const TileOrg& t, RegSet& RS) {
+        const AT* ib = addr(t);
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) load_item(k, ib, RS);
     };
     auto store = [&](const TileOrg& t, int buf, const RegSet& RS) {
-        auto& R = RS.v;
         int iy0, ix0; origin(t, iy0, ix0);
 #pragma unroll
-        for (int k = 0; k < NSLOT; ++k) {
-            const float4 v0 = widen4(R[k][0]), v1 = widen4(R[k][1]);
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const int gy = iy0 + sly[k], gx = ix0 + slx[k];
-            const bool in = gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi;
-            act8(v, fa, fb, lo, in);
-            uint4 pl[NS];
-            split8<NS>(v, pl);
-            char* d = smem + buf * IN_B + sdst[k];
-#pragma unroll
-            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * PLANE_B) = pl[p];
-        }
+        for (int k = 0; k < NSLOT; ++k) store_item(k, iy0, ix0, buf, RS);
     };
 
     // ---- per-lane B-fragment geometry: K-slice kg of group g = tap g * TPM + kg / OCT, channel octet kg % OCT ----
@@ -954,26 +966,22 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
     float s1[ACC] = {0.f, 0.f, 0.f, 0.f}, s2[ACC] = {0.f, 0.f, 0.f, 0.f};
     TileWalk<TH, TW> walk;
     walk.init(A.tiles, A.tiles_x, A.total_tiles);
-    // Global loads run one tile ahead in registers.  (Two tiles ahead -- DEEP -- was measured: the second register set
-    // costs a resident block per CU at 8 channels and pushes the 16-channel mask epilogue past its register budget:
-    // 1.33 -> 1.49 ms over the thin layers of a step.)
-    constexpr bool DEEP = false;                             // (also measured for bf16 storage, where a set is half the size: 5.16 -> 5.35 ms at cfg-C)
-    RegSet R0, R1;
+    // Global loads run one tile ahead in registers.  (Two tiles ahead was measured twice: the second register set costs
+    // a resident block per CU at 8 channels and pushes the 16-channel mask epilogue past its register budget: 1.33 ->
+    // 1.49 ms over the thin layers of a step; with the two-pixel form, where it fits: 1.12 -> 1.15.)
+    RegSet R0;
     TileOrg cur = walk.first(A.tiles);
     if (walk.tl0 < walk.tlend) {
         const TileOrg n1 = walk.tl0 + walk.step < walk.tlend ? walk.next(cur) : cur;
-        const TileOrg n2 = walk.tl0 + 2 * walk.step < walk.tlend ? walk.next(n1) : n1;
         load(cur, R0);
         store(cur, 0, R0);
         load(n1, R0);
-        if constexpr (DEEP) load(n2, R1);
     }
     __syncthreads();
     int buf = 0;
     for (int tl = walk.tl0; tl < walk.tlend; tl += walk.step, buf ^= 1) {
         const TileOrg nxt = tl + walk.step < walk.tlend ? walk.next(cur) : cur;
         const TileOrg nx2 = tl + 2 * walk.step < walk.tlend ? walk.next(nxt) : nxt;
-        const TileOrg nx3 = tl + 3 * walk.step < walk.tlend ? walk.next(nx2) : nx2;
         const int b = cur.b, y0 = cur.ty * TH, x0 = cur.tx * TW;
         const size_t tbase = (((size_t)b * A.Ho + y0) * A.Wo + x0) * A.Mout;       // wave-uniform element offset of the tile
         bool pvalid[NTW];
@@ -988,13 +996,14 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) zq[nt] = ldraw4<AT>(zb + (pvalid[nt] ? ooff[nt] : 0));   // (tile origin is in range)
         }
-        store(nxt, buf ^ 1, R0);                                // (a dummy repeat behind the last tile: branch-free body)
-        if constexpr (DEEP) { R0 = R1; load(nx3, R1); }
-        else load(nx2, R0);
+        const AT* const ib2 = addr(nx2);                       // item addresses of tile t+2 (the branch stays out of the MFMA block)
+        int iy1, ix1; origin(nxt, iy1, ix1);                   // tile t+1 is in R0 (a dummy repeat behind the last tile: branch-free body)
         f32x4 acc[NTW];
         const char* Ib = smem + buf * IN_B;
         {   // flat sequence of (pixel group, K group) steps; the B fragments of step s+2 are requested before the MFMAs of
-            // step s issue (ring of 3 fragment sets): an LDS round trip is longer than the 6 MFMAs of one step
+            // step s issue (ring of 3 fragment sets): an LDS round trip is longer than the 6 MFMAs of one step.  The staging
+            // items of tile t+1 (registers -> LDS, other buffer) and the loads of tile t+2 into the freed registers sit in
+            // program order BEHIND the fragment reads of their step: an LDS write may not move above a read it might alias.
             constexpr int STEPS = NTW * NG, DEPTH = 3;
             bf16x8 bv[DEPTH][NS];
             auto fetch = [&](int st, bf16x8 (&f)[NS]) {
@@ -1019,18 +1028,28 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
                 }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], b[0], c, 0, 0, 0);
                 if (g == NG - 1) { acc[st / NG] = c; c = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int k = 0; k < NSLOT; ++k)
+                    if ((k * STEPS) / NSLOT == st) { store_item(k, iy1, ix1, buf ^ 1, R0); load_item(k, ib2, R0); }
             }
-            // pin the schedule of this basic block (hipcc otherwise sinks every LDS read next to its use): fragments two
-            // steps ahead, then the step's MFMAs with a share of the next tile's conversion VALU in their shadow
-            constexpr int NPROD = NS == 3 ? 6 : 1, VPS = (NS == 3 ? 16 : 8) * (M2 ? 2 : 1);
-            constexpr int WEVERY = (M2 && CT == 8) ? 2 : 4;     // LDS writes of the next tile: spread over the steps
+            // pin the schedule of this basic block (hipcc otherwise sinks every LDS read next to its use and emits the
+            // whole conversion in front of the MFMAs): per step the fragments two steps ahead, the step's MFMAs, a share
+            // of the conversion VALU in their shadow, and behind an item its LDS writes and the two loads that refill it
+            constexpr int NPROD = NS == 3 ? 6 : 1;
+            constexpr int VPS = (NSLOT * (NS == 3 ? 60 : 36) + STEPS - 1) / STEPS;
             __builtin_amdgcn_sched_group_barrier(0x100, STEPS > 1 ? 2 * NS : NS, 0);
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 if (st + 2 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, VPS, 0);
-                if (st % WEVERY == WEVERY - 1) __builtin_amdgcn_sched_group_barrier(0x200, NS, 0);
+                bool item = false;
+#pragma unroll
+                for (int k = 0; k < NSLOT; ++k) item = item || (k * STEPS) / NSLOT == st;
+                if (item) {
+                    __builtin_amdgcn_sched_group_barrier(0x200, NS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                }
             }
         }
         // ---- epilogue of this tile: lane holds channels m4..m4+3 of pixel (row 2 wave + nt/2, x = 16 (nt&1) + px) ----
