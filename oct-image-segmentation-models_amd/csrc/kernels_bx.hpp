@@ -1174,62 +1174,73 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
         b = tl / A.tiles; const int t = tl % A.tiles;
         x0 = (t % A.tiles_x) * TW; y0 = (t / A.tiles_x) * TH;
     };
-    auto load = [&](int tl, Regs& R) {                                       // unconditional: addresses clamped into the image
-        int b, y0, x0; tile_of(tl, b, y0, x0);
-#pragma unroll
-        for (int k = 0; k < NXS; ++k) {
-            int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;
+    // staging in ITEM form (one (pixel, octet) of X or of dz per thread), unconditional loads with addresses clamped into
+    // the image: the tile loop places the items of the next tiles between its MFMA steps (see conv_dwbx_k)
+    struct Geo { int b, y0, x0; };
+    auto geo_of = [&](int tl) { Geo g; tile_of(tl, g.b, g.y0, g.x0); return g; };
+    constexpr int NIT = NXS + NDS;
+    auto load_item = [&](int i, const Geo& g, Regs& R) {
+        if (i < NXS) {
+            const int k = i;
+            int gy = g.y0 + xly[k] - PT, gx = g.x0 + xlx[k] - PT;
             gy = gy < 0 ? 0 : (gy >= A.H ? A.H - 1 : gy); gx = gx < 0 ? 0 : (gx >= A.W ? A.W - 1 : gx);
             const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
-            const AT* p = xsrc + (((size_t)b * Hs + sy) * Ws + sx) * Cs;
+            const AT* p = xsrc + (((size_t)g.b * Hs + sy) * Ws + sx) * Cs;
             R.x[k][0] = ldraw4<AT>(p); R.x[k][1] = ldraw4<AT>(p + 4);
-        }
-#pragma unroll
-        for (int k = 0; k < NDS; ++k) {
+        } else {
+            const int k = i - NXS;
             const int P = tid / OD + k * PPD;
-            int py = y0 + P / TW, px = x0 + P % TW;
+            int py = g.y0 + P / TW, px = g.x0 + P % TW;
             py = py >= A.H ? A.H - 1 : py; px = px >= A.W ? A.W - 1 : px;
-            const AT* p = dsrc + (((size_t)b * A.H + py) * A.W + px) * A.Cout;
+            const AT* p = dsrc + (((size_t)g.b * A.H + py) * A.W + px) * A.Cout;
             R.d[k][0] = ldraw4<AT>(p); R.d[k][1] = ldraw4<AT>(p + 4);
         }
     };
-    auto store = [&](int tl, const Regs& R, int buf, bool live) {
-        int b, y0, x0; tile_of(tl, b, y0, x0);
-        char* const Xb = smem + buf * BUF_B + cx * 2;
-        char* const Db = smem + buf * BUF_B + NS * XPL + od * 16;
-#pragma unroll
-        for (int k = 0; k < NXS; ++k) {
+    auto store_item = [&](int i, const Geo& g, const Regs& R, int buf, bool live) {
+        if (i < NXS) {
+            const int k = i;
             const float4 v0 = widen4(R.x[k][0]), v1 = widen4(R.x[k][1]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const int gy = y0 + xly[k] - PT, gx = x0 + xlx[k] - PT;
+            const int gy = g.y0 + xly[k] - PT, gx = g.x0 + xlx[k] - PT;
             const bool in = gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
             act8(v, fa, fb, lo, in);
             if constexpr (DROP) {              // (only the up-conv behind the bottleneck; compile-time: a runtime branch here
                                                //  would cut the conversion out of the basic block that holds the MFMAs)
                 const int sy = UP ? gy >> 1 : gy, sx = UP ? gx >> 1 : gx;
-                const uint32_t el = (uint32_t)((((size_t)b * Hs + sy) * Ws + sx) * Cs + ccx);
+                const uint32_t el = (uint32_t)((((size_t)g.b * Hs + sy) * Ws + sx) * Cs + ccx);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = in ? v[i] * drop_mul(A.drop, el + i) : 0.f;
+                for (int e = 0; e < 8; ++e) v[e] = in ? v[e] * drop_mul(A.drop, el + e) : 0.f;
             }
             uint4 pl[NS];
             split8<NS>(v, pl);
             const int P = tid / OX + k * PPX;
+            char* d = smem + buf * BUF_B + cx * 2 + P * XPB;
 #pragma unroll
-            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(Xb + P * XPB + p * XPL) = pl[p];
-        }
-#pragma unroll
-        for (int k = 0; k < NDS; ++k) {
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * XPL) = pl[p];
+        } else {
+            const int k = i - NXS;
             const int P = tid / OD + k * PPD;
-            const bool in = live && P < NPD && y0 + P / TW < A.H && x0 + P % TW < A.W;
+            const bool in = live && P < NPD && g.y0 + P / TW < A.H && g.x0 + P % TW < A.W;
             const float4 v0 = widen4(R.d[k][0]), v1 = widen4(R.d[k][1]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { v[i] = in ? v[i] : 0.f; bsum[i] += v[i]; }
+            for (int e = 0; e < 8; ++e) { v[e] = in ? v[e] : 0.f; bsum[e] += v[e]; }
             uint4 pl[NS];
             split8<NS>(v, pl);
+            char* d = smem + buf * BUF_B + NS * XPL + od * 16 + P * DPB;
 #pragma unroll
-            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(Db + P * DPB + p * DPL) = pl[p];
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * DPL) = pl[p];
         }
+    };
+    auto load = [&](int tl, Regs& R) {
+        const Geo g = geo_of(tl);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) load_item(i, g, R);
+    };
+    auto store = [&](int tl, const Regs& R, int buf, bool live) {
+        const Geo g = geo_of(tl);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) store_item(i, g, R, buf, live);
     };
 
     f32x4 acc[NACC];
@@ -1245,21 +1256,29 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
         const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 4 * pitch));
         return bf16x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     };
-    auto compute = [&](int buf) {
+    // steps = A tiles; the A fragments of step s+2 are requested before the MFMAs of step s (ring of 3), the B fragments
+    // of the tile up front; staging items of the next tiles sit behind the fragment reads of their step
+    auto compute = [&](int buf, auto&& between) {
         const char* Xl = smem + buf * BUF_B + xlane;
         const char* Dl = smem + buf * BUF_B + NS * XPL + dlane + (wave * TW) * DPB;
-        bf16x8 bv[NTILES][NS];
+        constexpr int DEPTH = 3;
+        bf16x8 bv[NTILES][NS], av[DEPTH][NS];
+        auto fetch_a = [&](int mt, bf16x8 (&f)[NS]) {
+            const int ky = mt / MTX, mx = mt % MTX;
+            const int kx = CI == 8 ? 2 * mx : mx / (CI / 16), cb = CI == 8 ? 0 : (mx % (CI / 16)) * 16;   // tap column, channel base
+#pragma unroll
+            for (int p = 0; p < NS; ++p) f[p] = trx(Xl + p * XPL + ((wave + ky) * IW + kx) * XPB + cb * 2, XPB);
+        };
 #pragma unroll
         for (int nt = 0; nt < NTILES; ++nt)
 #pragma unroll
             for (int p = 0; p < NS; ++p) bv[nt][p] = trx(Dl + p * DPL + nt * 32, DPB);
+        fetch_a(0, av[0]);
+        if (MTILES > 1) fetch_a(1, av[1]);
 #pragma unroll
         for (int mt = 0; mt < MTILES; ++mt) {
-            const int ky = mt / MTX, mx = mt % MTX;
-            const int kx = CI == 8 ? 2 * mx : mx / (CI / 16), cb = CI == 8 ? 0 : (mx % (CI / 16)) * 16;   // tap column, channel base
-            bf16x8 a[NS];
-#pragma unroll
-            for (int p = 0; p < NS; ++p) a[p] = trx(Xl + p * XPL + ((wave + ky) * IW + kx) * XPB + cb * 2, XPB);
+            if (mt + 2 < MTILES) fetch_a(mt + 2, av[(mt + 2) % DEPTH]);
+            const bf16x8 (&a)[NS] = av[mt % DEPTH];
 #pragma unroll
             for (int nt = 0; nt < NTILES; ++nt) {
                 f32x4 c = acc[mt * NTILES + nt];
@@ -1272,6 +1291,20 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
                 }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bv[nt][0], c, 0, 0, 0);
                 acc[mt * NTILES + nt] = c;
+            }
+            between(mt);
+        }
+        constexpr int NPROD = (NS == 3 ? 6 : 1) * NTILES, RPF = 2 * NS;
+        constexpr int VPS = (NIT * (NS == 3 ? 60 : 36) + MTILES - 1) / MTILES, IPS = (NIT + MTILES - 1) / MTILES;   // items per step (at most)
+        __builtin_amdgcn_sched_group_barrier(0x100, (NTILES + (MTILES > 1 ? 2 : 1)) * RPF, 0);
+#pragma unroll
+        for (int mt = 0; mt < MTILES; ++mt) {
+            if (mt + 2 < MTILES) __builtin_amdgcn_sched_group_barrier(0x100, RPF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPS, 0);
+            if (((mt + 1) * NIT) / MTILES != (mt * NIT) / MTILES) {
+                __builtin_amdgcn_sched_group_barrier(0x200, NS * IPS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2 * IPS, 0);
             }
         }
     };
@@ -1287,9 +1320,16 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
     int buf = 0;
     for (int tl = t0; tl < tend; tl += step, buf ^= 1) {
         const int t1 = tl + step, t2 = tl + 2 * step;
-        store(t1 < tend ? t1 : tlast, R, buf ^ 1, t1 < tend);
-        load(t2 < tend ? t2 : tlast, R);
-        compute(buf);
+        const Geo g1 = geo_of(t1 < tend ? t1 : tlast), g2 = geo_of(t2 < tend ? t2 : tlast);
+        const bool live = t1 < tend;
+        compute(buf, [&](int mt) {                           // items [mt NIT / MTILES, (mt + 1) NIT / MTILES) behind step mt
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+                if (i >= (mt * NIT) / MTILES && i < ((mt + 1) * NIT) / MTILES) {
+                    store_item(i, g1, R, buf ^ 1, live);     // tile t+1: registers -> split -> LDS (other buffer)
+                    load_item(i, g2, R);                     // tile t+2: the same registers, requested right away
+                }
+        });
         __syncthreads();
     }
 
