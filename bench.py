@@ -154,8 +154,9 @@ def family(kernel_name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed steps before the timed region (the GPU clock governor needs tens of ms from idle)")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=512)
