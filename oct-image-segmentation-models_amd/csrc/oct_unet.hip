@@ -216,9 +216,10 @@ DwPlan dw_plan(const Layer& l, int B, int mfma_mode, int bf16) {
         p.npb = std::max(1, std::min(B * p.tiles, cdiv(g_dwbx_blocks, p.chunks)));
         return p;
     }
-    // fp32 mode: the three-term split of both operands makes conv_dwbt_k VALU-bound; it only beats the fp32-pipe kernels
-    // at 16 input channels (measured per shape, B=32 256x512).  bf16 mode (one rounding, one product): every thin shape.
-    if (mfma_mode && dwbt_ok(l) && (bf16 || g_dwbt_f32_all || (l.src != SRC_UP && l.cin == 16 && l.cout >= 16))) {
+    // fp32 mode: the three-term split of both operands makes conv_dwbt_k VALU-bound; measured per shape (B=32 256x512,
+    // us, fp32-pipe kernel vs this one): 8->8 89 / 100, up-convs 98 / 113 and 55 / 66 stay on the fp32 pipe; 16->8 149 /
+    // 143, 32->16 103 / 92, 8->16 39 / 35, 16->16 59 / 48, 16->32 come here.  bf16 mode (one rounding, one product): all.
+    if (mfma_mode && dwbt_ok(l) && (bf16 || g_dwbt_f32_all || (l.src != SRC_UP && !(l.cin == 8 && l.cout == 8)))) {
         // thin layers on the bf16 pipe (conv_dwbt_k): one block holds all channels; 1 or 2 blocks per CU (LDS images)
         p.kind = 34; p.cic = l.cin; p.coc = l.cout; p.th = 4; p.chunks = 1;
         p.tiles = cdiv(l.H, p.th) * cdiv(l.W, kTileX);
