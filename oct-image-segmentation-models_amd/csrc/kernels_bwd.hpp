@@ -252,13 +252,29 @@ __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
     const float scale = (1.f - A.focal_w) * (A.macro ? A.loss_scale / (float)(A.B * C) : A.loss_scale);
     const float fscale = A.focal_w * A.loss_scale * A.inv_count;
 
+    const AT* const zbase = reinterpret_cast<const AT*>(A.z) + (size_t)b * A.HW * CIN;
+    auto pix_of = [&](int chunk) { const int px = chunk * kBlock + threadIdx.x; return px < A.HW ? px : 0; };
+    float zn[CIN];
+    int labn = 0;
+    if ((int)blockIdx.x * kBlock < A.HW) {
+        const int q = pix_of(blockIdx.x);
+        head_load<CIN, AT>(zbase + (size_t)q * CIN, zn);
+        labn = A.labels[(size_t)b * A.HW + q];
+    }
     for (int chunk = blockIdx.x; chunk * kBlock < A.HW; chunk += gridDim.x) {
         const int px = chunk * kBlock + threadIdx.x;
         const bool valid = px < A.HW;
         const size_t pix = (size_t)b * A.HW + (valid ? px : 0);
         float y[CIN], zr[CIN], p[C];
-        head_logits<C, CIN, AT>(reinterpret_cast<const AT*>(A.z) + pix * CIN, A.bn, A.w, A.bias, y, zr, p);
-        const int lab = A.labels[pix];
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) zr[i] = zn[i];
+        const int lab = labn;
+        if ((chunk + (int)gridDim.x) * kBlock < A.HW) {          // the next chunk's pixel is requested before this one is used
+            const int q = pix_of(chunk + gridDim.x);
+            head_load<CIN, AT>(zbase + (size_t)q * CIN, zn);
+            labn = A.labels[(size_t)b * A.HW + q];
+        }
+        head_logits<C, CIN>(A.bn, A.w, A.bias, y, zr, p);
         float dp[C], dot = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {

@@ -291,15 +291,20 @@ struct HeadFwdArgs {
 };
 constexpr float kFocalEps = 1e-7f;
 
-template <int C, int CIN, typename AT>
-__device__ inline void head_logits(const AT* __restrict__ zp, const float* __restrict__ ab,
-                                   const float* __restrict__ w, const float* __restrict__ bias,
-                                   float (&y)[CIN], float (&zr)[CIN], float (&p)[C]) {
+// raw z of one pixel (CIN values) -> registers; split from the arithmetic so that the head kernels can request the next
+// chunk's pixel before they work on the current one (one chunk of software prefetch)
+template <int CIN, typename AT>
+__device__ inline void head_load(const AT* __restrict__ zp, float (&zr)[CIN]) {
 #pragma unroll
     for (int i = 0; i < CIN; i += 4) {
         const float4 v = lda4<AT>(zp + i);
         zr[i] = v.x; zr[i + 1] = v.y; zr[i + 2] = v.z; zr[i + 3] = v.w;
     }
+}
+
+template <int C, int CIN>
+__device__ inline void head_logits(const float* __restrict__ ab, const float* __restrict__ w, const float* __restrict__ bias,
+                                   float (&y)[CIN], const float (&zr)[CIN], float (&p)[C]) {
 #pragma unroll
     for (int i = 0; i < CIN; ++i) y[i] = fmaxf(fmaf(ab[i], zr[i], ab[CIN + i]), 0.f);
     float mx = -3.4e38f;
@@ -333,7 +338,8 @@ __global__ __launch_bounds__(kBlock) void head_fwd_k(const HeadFwdArgs A) {
         const bool valid = px < A.HW;
         const size_t pix = (size_t)b * A.HW + (valid ? px : 0);
         float y[CIN], zr[CIN], p[C];
-        head_logits<C, CIN, AT>(reinterpret_cast<const AT*>(A.z) + pix * CIN, A.ab, A.w, A.bias, y, zr, p);
+        head_load<CIN, AT>(reinterpret_cast<const AT*>(A.z) + pix * CIN, zr);   // (a chunk of prefetch was measured here: slower)
+        head_logits<C, CIN>(A.ab, A.w, A.bias, y, zr, p);
         if (valid) {
             if (A.probs) {
 #pragma unroll
