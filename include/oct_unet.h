@@ -175,6 +175,9 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   "bt_blocks_per_cu" (0 = as many as the LDS images allow): persistent blocks of the thin bf16-pipe kernel.
  *   "bt_m2" (1): thin bf16-pipe launches with exactly 8 output channels use the two-pixel form (16 MFMA rows = 2 adjacent
  *   pixels x 8 channels); read when the handle is created (the weights are prepared in that form).  0 = one pixel per column.
+ *   "fuse_first_apply" (1): the first conv's BN-backward transform is applied inside its backward-weights kernel (the
+ *   only consumer of that dz) instead of by a bn_bwd_apply pass; bit-identical gradients; oct_unet_debug_activation(0, 1)
+ *   then returns the masked gradient g' of block 0, not dz.  0 = separate pass.
  *   "dwbt_f32_all" (0): 1 = fp32 mode takes conv_dwbt_k for every thin backward-weights shape (default: where it wins).
  *   "dw_side_stream" (1): backward-weights kernels and the per-step weight preparation run on a low-priority stream
  *   owned by the handle, beside the backward-data chain.  0 = everything on the caller's stream.

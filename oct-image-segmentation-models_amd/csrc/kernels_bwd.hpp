@@ -169,6 +169,14 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_finalize_k(const BnBwdFinArgs A
     }
 }
 
+// the BN-backward transform of one element, in ONE place and with its one fma written out, so that the stand-alone pass
+// and the copy fused into conv_dw_first_k produce the same bits
+__device__ __forceinline__ float bn_bwd_apply1(float gm, float rstd, float c1, float c2, float mean, float g, float z) {
+    const float xh = (z - mean) * rstd;                    // (a product that only feeds products / an explicit fma: nothing
+    const float w = fmaf(-xh, c2, g - c1);                 //  is left for the compiler to contract differently per call site)
+    return (gm * rstd) * w;
+}
+
 // dz = gamma*rstd*(g' - c1 - xhat*c2), in place over g'
 template <typename AT>
 __global__ __launch_bounds__(kBlock) void bn_bwd_apply_k(AT* __restrict__ g, const AT* __restrict__ z,
@@ -180,10 +188,10 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_k(AT* __restrict__ g, con
         const float4 mean = ld4(bn + BN_MEAN * C + c), rstd = ld4(bn + BN_RSTD * C + c);
         const float4 c1 = ld4(bn + BN_C1 * C + c), c2 = ld4(bn + BN_C2 * C + c), gm = ld4(gamma + c);
         float4 o;
-        o.x = gm.x * rstd.x * (gv.x - c1.x - (zv.x - mean.x) * rstd.x * c2.x);
-        o.y = gm.y * rstd.y * (gv.y - c1.y - (zv.y - mean.y) * rstd.y * c2.y);
-        o.z = gm.z * rstd.z * (gv.z - c1.z - (zv.z - mean.z) * rstd.z * c2.z);
-        o.w = gm.w * rstd.w * (gv.w - c1.w - (zv.w - mean.w) * rstd.w * c2.w);
+        o.x = bn_bwd_apply1(gm.x, rstd.x, c1.x, c2.x, mean.x, gv.x, zv.x);
+        o.y = bn_bwd_apply1(gm.y, rstd.y, c1.y, c2.y, mean.y, gv.y, zv.y);
+        o.z = bn_bwd_apply1(gm.z, rstd.z, c1.z, c2.z, mean.z, gv.z, zv.z);
+        o.w = bn_bwd_apply1(gm.w, rstd.w, c1.w, c2.w, mean.w, gv.w, zv.w);
         sta4<AT>(g + i * 4, o);
     }
 }
@@ -205,10 +213,10 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply8_bf16_k(bf16_t* __restric
             const float4 mean = ld4(bn + BN_MEAN * C + cc), rstd = ld4(bn + BN_RSTD * C + cc);
             const float4 c1 = ld4(bn + BN_C1 * C + cc), c2 = ld4(bn + BN_C2 * C + cc), gm = ld4(gamma + cc);
             float4 o;
-            o.x = gm.x * rstd.x * (gv[hlf].x - c1.x - (zv[hlf].x - mean.x) * rstd.x * c2.x);
-            o.y = gm.y * rstd.y * (gv[hlf].y - c1.y - (zv[hlf].y - mean.y) * rstd.y * c2.y);
-            o.z = gm.z * rstd.z * (gv[hlf].z - c1.z - (zv[hlf].z - mean.z) * rstd.z * c2.z);
-            o.w = gm.w * rstd.w * (gv[hlf].w - c1.w - (zv[hlf].w - mean.w) * rstd.w * c2.w);
+            o.x = bn_bwd_apply1(gm.x, rstd.x, c1.x, c2.x, mean.x, gv[hlf].x, zv[hlf].x);
+            o.y = bn_bwd_apply1(gm.y, rstd.y, c1.y, c2.y, mean.y, gv[hlf].y, zv[hlf].y);
+            o.z = bn_bwd_apply1(gm.z, rstd.z, c1.z, c2.z, mean.z, gv[hlf].z, zv[hlf].z);
+            o.w = bn_bwd_apply1(gm.w, rstd.w, c1.w, c2.w, mean.w, gv[hlf].w, zv[hlf].w);
             sta4<bf16_t>(out + 4 * hlf, o);       // the two 8-byte halves of one 16-byte line: merged by the compiler / L2
         }
     }
@@ -330,6 +338,8 @@ struct ConvBwdWArgs {
     const void* x1; const float* ab1; int C1;
     int flags;                                  // F_* (runtime here: staging is outside the FMA loop)
     const void* dz;                             // (B,H,W,Cout), activation storage type
+    const void* zf; const float* bnf; const float* gammaf;   // first layer only, fused BN-backward transform: `dz` is the
+                                                // masked gradient g', dz = gamma*rstd*(g' - c1 - xhat*c2) is formed on load
     float* part;                                // [npb][KH*KW*Cin*Cout + Cout]
     int B, H, W, Cin, Cout, tiles_x, tiles, total_tiles, npb;
     DropCfg drop;
@@ -420,7 +430,10 @@ __global__ __launch_bounds__(kBlock) void conv_bwd_w_k(const ConvBwdWArgs A) {
 // Pure streaming reduction over dz (32 B/pixel, read straight from global memory, fully coalesced) against the image tile
 // in LDS; every thread keeps all 72 weight + 8 bias sums in registers, one block reduction per persistent block.
 // grid (npb); partial slab layout [tap][co] (72) + bias (8) = the generic [tap][ci][co] + bias layout for Cin = 1.
-template <typename AT>
+// FUSE: the BN-backward transform of this layer is applied here instead of by bn_bwd_apply_k (same expression, same
+// operation order): nothing else consumes this layer's dz -- the input image has no gradient -- so the 3-tensor pass
+// over the largest tensor of the net disappears from the backward-data chain (66 us of a 4.2 ms step).
+template <typename AT, bool FUSE>
 __global__ __launch_bounds__(kBlock) void conv_dw_first_k(const ConvBwdWArgs A, int tiles_x, int tiles, int total_tiles) {
     constexpr int TH = 8, TW = 128, XH = TH + 2, XW = TW + 2;
     __shared__ float Xs[XH * XW];
@@ -461,9 +474,23 @@ __global__ __launch_bounds__(kBlock) void conv_dw_first_k(const ConvBwdWArgs A, 
         for (int k = 0; k < TW / 32; ++k) {
             const int xx = xl + 32 * k, x = x0 + xx;
             if (y < A.H && x < A.W) {
-                const AT* dp = reinterpret_cast<const AT*>(A.dz) + (((size_t)b * A.H + y) * A.W + x) * 8;
+                const size_t e8 = (((size_t)b * A.H + y) * A.W + x) * 8;
+                const AT* dp = reinterpret_cast<const AT*>(A.dz) + e8;
                 const float4 d0 = lda4<AT>(dp), d1 = lda4<AT>(dp + 4);
-                const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                if constexpr (FUSE) {
+                    const AT* zp = reinterpret_cast<const AT*>(A.zf) + e8;
+                    const float4 z0 = lda4<AT>(zp), z1 = lda4<AT>(zp + 4);
+                    const float zv[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+#pragma unroll
+                    for (int co = 0; co < 8; ++co) {      // bn_bwd_apply_k's expression; bf16 storage: dz is rounded as it would be stored
+                        const float o = bn_bwd_apply1(A.gammaf[co], A.bnf[BN_RSTD * 8 + co], A.bnf[BN_C1 * 8 + co], A.bnf[BN_C2 * 8 + co],
+                                                      A.bnf[BN_MEAN * 8 + co], d[co], zv[co]);
+                        d[co] = sizeof(AT) == 2 ? bf2f(f2bf(o)) : o;
+                        asm volatile("" : "+v"(d[co]));      // dz is a ROUNDED value (as if stored): its last product must not be
+                                                             // contracted into the sums below
+                    }
+                }
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const float xv = Xs[(row + tap / 3) * XW + xx + tap % 3];

@@ -32,6 +32,7 @@ int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10
 int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
 int g_dw_side_stream = 1;          // backward-weights kernels on the handle's side stream beside the backward-data chain
 int g_bx_waves = 8;                // waves per block of conv_bx_k where the tile has >= 8 rows: 8 = two per SIMD, 4 = one per SIMD
+int g_fuse_first_apply = 1;        // the first conv's BN-backward transform is applied inside its backward-weights kernel
 int g_bt_m2 = 1;                   // conv_bt_k: 8-output-channel launches in the two-pixel form (fixed per engine at create)
 int g_dwbt_f32_all = 0;            // 1: fp32 mode also takes conv_dwbt_k for every thin shape (tests exercise all instantiations)
 int g_bt_blocks_per_cu = 0;        // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows: 3 / 2 / 1 at 8 / 16 / 32 input channels)
@@ -787,7 +788,13 @@ int flush_reduce(oct_unet* h, hipStream_t s) {
     return 0;
 }
 
-int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const void* dz, int B, hipStream_t s) {
+// the real first layer (1 -> 8 channels, 3x3, image input): streaming backward-weights kernel; it can apply the layer's
+// BN-backward transform itself (nothing else reads that dz)
+inline bool first_dw_streams(const Layer& l) {
+    return l.src == SRC_INPUT && l.cin == 1 && l.cout == 8 && l.kh == 3 && l.has_bn && !l.drop_in;
+}
+
+int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const void* dz, int B, hipStream_t s, bool fused_apply = false) {
     const Layer& l = h->plan.L[li];
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
     DwPlan p = dw_plan(l, B, g_mfma_mode, h->cfg.dtype);
@@ -810,9 +817,16 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
         const int grid = std::min(total, a.npb);
         a.npb = grid;
         const int bf = a.act_bf16;
-        ProfScope ps(s, bf ? "conv_dw_first_k<unsigned short>" : "conv_dw_first_k<float>", l.name, fl, by);
-        AT_DISPATCH(bf, conv_dw_first_k<AT><<<grid, kBlock, 0, s>>>(a, tx, tiles, total));
+        ProfScope ps(s, bf ? "conv_dw_first_k<unsigned short>" : "conv_dw_first_k<float>", l.name, fl, by + (fused_apply ? px * l.cout * es : 0));
+        if (fused_apply) {
+            a.zf = l.z; a.bnf = l.bn; a.gammaf = h->params + l.gamma_off;
+            AT_DISPATCH(bf, (conv_dw_first_k<AT, true><<<grid, kBlock, 0, s>>>(a, tx, tiles, total)));
+        } else {
+            AT_DISPATCH(bf, (conv_dw_first_k<AT, false><<<grid, kBlock, 0, s>>>(a, tx, tiles, total)));
+        }
         HIP_OK(hipGetLastError());
+    } else if (fused_apply) {
+        return fail(-3, "conv_backward_w: fused BN-backward apply is only built into the streaming first-layer kernel");
     } else if (p.kind == 0) {
         rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by);   // other 1-channel / odd-channel first layers
     } else if (p.kind == 34) {
@@ -868,13 +882,14 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
 }
 
 // finalize + apply BN backward for block li (its g buffer holds masked gradients, stat_part the partials)
-int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s) {
+int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s, bool finalize_only = false) {
     const Layer& l = h->plan.L[li];
     BnBwdFinArgs f{};
     f.part = h->stat_part; f.nblk = nblk; f.C = l.cout; f.count = (double)B * l.H * l.W;
     f.bn = l.bn; f.dgamma = h->grads + l.gamma_off; f.dbeta = h->grads + l.beta_off;
     { ProfScope ps(s, "bn_bwd_finalize_k", l.name, 0, (double)nblk * 2 * l.cout * 4);
       bn_bwd_finalize_k<<<l.cout, kBlock, 0, s>>>(f); }
+    if (finalize_only) { HIP_OK(hipGetLastError()); return 0; }      // the consumer applies the transform itself
     const size_t n4 = (size_t)B * l.H * l.W * l.cout / 4;
     const int grid = (int)std::min<size_t>((n4 + kBlock - 1) / kBlock, 8192);
     const int bf = h->cfg.dtype;
@@ -935,17 +950,20 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     for (int li = nl - 2; li >= 0; --li) {
         Layer& l = pl.L[li];
         // g buffer of block li is complete (+ partials in stat_part) -> dz in place
-        rc = bn_backward(h, li, pending_nblk, B, s);
+        // (first layer: its dz has ONE consumer, the backward-weights kernel, which then applies the transform on load)
+        const bool fuse0 = g_fuse_first_apply && li == 0 && first_dw_streams(l) && dw_plan(l, B, g_mfma_mode, h->cfg.dtype).kind == 0 &&
+                           !(src_of(h, li, x_in, x_is_u8).flags & (F_AFF | F_DROP | F_TWO | F_UP));
+        rc = bn_backward(h, li, pending_nblk, B, s, fuse0);
         if (rc) return rc;
         const bool fork = side_ok;     // (the per-launch profiler wants serial launches)
         if (fork) {
             hipEvent_t e = h->fork_ev[1 + li % (h->fork_ev.size() - 1)];
             HIP_OK(hipEventRecord(e, s));                        // dz of block li is final here
             HIP_OK(hipStreamWaitEvent(h->side, e, 0));
-            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, h->side);
+            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, h->side, fuse0);
             forked = true;
         } else {
-            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s);
+            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s, fuse0);
         }
         if (rc) return rc;
         if (h->tail_event && li == first_mid_layer(pl)) {
@@ -1371,7 +1389,7 @@ const Opt k_opts[] = {
     {"dw16_blocks", &g_dw16_blocks, 64}, {"igemm_persistent_blocks", &g_igemm_p_blocks, 8},
     {"igemm_min_blocks", &g_igemm_min_blocks, 1}, {"dwpair8_enable", &g_dwpair8, 0},
     {"pair8_geometry", &g_pair_geo, 111}, {"pair8_min_tiles", &g_pair_min_tiles, 1}, {"thin8_min_tiles", &g_thin_min_tiles, 1},
-    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0}, {"dwbt_f32_all", &g_dwbt_f32_all, 0}, {"bt_m2", &g_bt_m2, 0}, {"bx_waves", &g_bx_waves, 4}, {"dw_side_stream", &g_dw_side_stream, 0},
+    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0}, {"dwbt_f32_all", &g_dwbt_f32_all, 0}, {"bt_m2", &g_bt_m2, 0}, {"fuse_first_apply", &g_fuse_first_apply, 0}, {"bx_waves", &g_bx_waves, 4}, {"dw_side_stream", &g_dw_side_stream, 0},
 };
 }  // namespace
 
@@ -1399,6 +1417,7 @@ int oct_set_option(const char* name, int value) {
     if (!strcmp(name, "bt_blocks_per_cu")) { g_bt_blocks_per_cu = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "dwbt_f32_all")) { g_dwbt_f32_all = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bt_m2")) { g_bt_m2 = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "fuse_first_apply")) { g_fuse_first_apply = value ? 1 : 0; return 0; }
     if (!strcmp(name, "dw_side_stream")) { g_dw_side_stream = value ? 1 : 0; return 0; }
     if (!strcmp(name, "bx_waves")) { if (value != 4 && value != 8) return fail(-1, "bx_waves must be 4 or 8"); g_bx_waves = value; return 0; }
     return fail(-1, std::string("unknown option: ") + name);

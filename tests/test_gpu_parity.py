@@ -57,7 +57,7 @@ DROP_STEP = 3
 
 
 @pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111", "dw16_padded",
-                        "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all", "bt_one_px"])
+                        "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all", "bt_one_px", "first_apply_separate"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant: for the thin layers the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels (otherwise only chosen on large grids); for the wide layers the
@@ -70,6 +70,7 @@ def variant(request):
     _hip.set_option("mfma_mode", 0 if v == "f32_pipe" else 1)
     _hip.set_option("dwbt_f32_all", 1 if v == "dwbt_all" else 0)     # fp32 mode: every thin dW shape on the bf16 pipe
     _hip.set_option("bt_m2", 0 if v == "bt_one_px" else 1)           # thin kernel: 8-channel launches without the two-pixel form
+    _hip.set_option("fuse_first_apply", 0 if v == "first_apply_separate" else 1)   # block 0: bn_bwd_apply as its own pass
     _hip.set_option("igemm_persistent_min_tiles", 1 if v == "persistent" else 1 << 30)
     _hip.set_option("thin8_min_tiles", 1 if v == "thin8_valu" or v.startswith("pair8") else 1 << 30)
     _hip.set_option("pair8_min_tiles", 1 if v.startswith("pair8") else 1 << 30)
@@ -81,6 +82,7 @@ def variant(request):
     _hip.set_option("mfma_mode", 1)
     _hip.set_option("dwbt_f32_all", 0)
     _hip.set_option("bt_m2", 1)
+    _hip.set_option("fuse_first_apply", 1)
     _hip.set_option("dwpair8_enable", 1)
     _hip.set_option("igemm_persistent_min_tiles", 2048)
     _hip.set_option("thin8_min_tiles", 2048)
@@ -151,7 +153,12 @@ def test_training_step_matches_oracle(case, macro, variant):
 
     loss, grads = on.backward(cfg, p64, cache, labels, macro=macro, loss_scale=0.5)
     # layer-wise dz from the last block backwards
-    for li in range(len(plan) - 2, -1, -1):
+    # (block 0 on the default route: its BN-backward transform is applied inside the backward-weights kernel, so its
+    # buffer keeps the masked gradient g' -- that dz is checked through the block's kernel / bias gradients below and
+    # directly in the "first_apply_separate" variant)
+    from oct_image_segmentation_models_amd import _hip
+    fused0 = _hip.get_option("fuse_first_apply") == 1 and ic == 1 and sn == 8
+    for li in range(len(plan) - 2, 0 if fused0 else -1, -1):
         dz = eng.debug_activation(li, 1)[:B].cpu().numpy()
         ref_dz = cache[li]["dz"]
         scale = np.abs(ref_dz).max()
@@ -444,6 +451,40 @@ def test_focal_dice_loss_and_gradients_match_oracle(macro, cw):
     assert torch.equal(g0, eng2.grads)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_first_block_fused_bn_backward_equals_the_separate_pass(dtype):
+    """Block 0's dz has one consumer (its backward-weights kernel; the image has no gradient), so by default the
+    BN-backward transform dz = gamma*rstd*(g' - c1 - xhat*c2) is applied inside conv_dw_first_k instead of by a
+    bn_bwd_apply pass over the largest tensor of the net.  Same expression, same rounding of dz to the storage type:
+    every gradient must equal the separate-pass route BIT FOR BIT, in fp32 and in bf16 storage."""
+    from oct_image_segmentation_models_amd import _hip
+    from oct_image_segmentation_models_amd.engine import UNetEngine
+    B, H, W, C = 3, 40, 96, 3                       # ragged against the 8 x 128 tile of the streaming kernel
+    images, labels = data(B, H, W, C, 1, seed=21)
+    x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+    got = {}
+    try:
+        for fuse in (1, 0):
+            _hip.set_option("fuse_first_apply", fuse)
+            eng = UNetEngine(device="cuda:0", input_channels=1, num_classes=C, image_height=H, image_width=W,
+                             start_neurons=8, pool_layers=3, max_batch=B, training=True, seed=9, init_seed=4,
+                             dtype="bfloat16" if dtype == "bf16" else "float32")
+            eng.set_dropout_step(2)
+            eng.profile_begin()
+            eng.forward(x, training=True, labels=lab, want_probs=False); eng.loss_dice(); eng.backward(lab, macro=True)
+            names = [(e["kernel"], e["layer"]) for e in eng.profile_end()]
+            applied0 = any(k.startswith("bn_bwd_apply") and l == "enc0.conv0" for k, l in names)
+            assert applied0 == (fuse == 0), names            # the pass is really gone / really there
+            got[fuse] = eng.grads.clone()
+            if fuse == 0:
+                dz0 = eng.debug_activation(0, 1)[:B].float().abs().sum().item()
+                assert dz0 > 0
+    finally:
+        _hip.set_option("fuse_first_apply", 1)
+    assert torch.isfinite(got[1]).all() and got[1].abs().max() > 0
+    assert torch.equal(got[0], got[1])
+
+
 @pytest.mark.parametrize("clip_mod", [0, 1])
 def test_focal_clip_modulation_switch(clip_mod):
     """The one focal-loss detail that cannot be verified here (does (1 - p_y)^gamma see the CLIPPED probability?) is a
@@ -629,7 +670,9 @@ def upconv_dx_effective(dz, kernel, round_w):
 
 @pytest.mark.parametrize("case", BF16_CASES)
 def test_bf16_storage_layer_local_rounding_is_exact(case, variant):
-    B, H, W, C, sn, P, L, ic = case
+    from oct_image_segmentation_models_amd import _hip
+    _hip.set_option("fuse_first_apply", 0)        # this test reads EVERY block's dz buffer, block 0 included (the fused
+    B, H, W, C, sn, P, L, ic = case               # route is pinned bit for bit against this one by the test below)
     cfg, eng, p64, s64 = make_bf16(B, H, W, C, sn, P, L, ic)
     assert eng.workspace.numel() < 0.8 * make(B, H, W, C, sn, P, L, ic)[1].workspace.numel()   # partials stay fp32
     images, labels = data(B, H, W, C, ic, seed=MARGIN_SEED.get(case, 5))
