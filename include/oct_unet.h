@@ -122,8 +122,10 @@ int oct_unet_backward(oct_unet* h, const unsigned char* labels_dev, int macro, f
  * runs head -> decoder -> bottleneck -> encoder.  With a tail event set, oct_unet_backward sums the partial slabs of
  * every layer from the first bottleneck conv on as soon as that conv's gradients are queued and records the event on
  * `stream`: floats [oct_unet_grad_tail_offset(cfg), param_count) of grads are final from then on, so the launcher can
- * all-reduce that segment on a side stream (after hipStreamWaitEvent) while the encoder backward still runs, and the
- * remaining head segment [0, offset) after backward.  hip_event: a hipEvent_t owned by the caller, NULL disables. */
+ * all-reduce that TAIL segment (bottleneck + decoder + head: 97 % of the floats) on a side stream (after
+ * hipStreamWaitEvent) while the encoder backward still runs, and the remaining ENCODER segment [0, offset) after
+ * backward.  hip_event: a hipEvent_t owned by the caller, NULL disables.  If oct_unet_backward returns an error the
+ * event may not have been recorded and the handle's internal side stream has been joined to `stream` before returning. */
 int    oct_unet_set_tail_event(oct_unet* h, void* hip_event);
 size_t oct_unet_grad_tail_offset(const oct_unet_cfg* cfg);
 
@@ -161,7 +163,11 @@ int oct_unet_profile_end(oct_unet* h, oct_profile_entry* out, int max_entries, i
 int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int n_cls, int bg_ilm, int bg_csi,
                       unsigned char* maps_dev, oct_stream_t stream);
 
-/* ---- options (process-wide) ----
+/* ---- options ----
+ * oct_set_option edits the PROCESS-WIDE DEFAULTS; a handle copies them when it is created (oct_unet_create) and every
+ * launch of that handle reads its own copy: changing an option never affects a live handle, and two handles created
+ * under different settings coexist in one process.  oct_unet_workspace_bytes uses the defaults current at the call, so
+ * size and create a handle under the same settings.  oct_unet_get_option reads a handle's copy.
  * Two select ARITHMETIC (documented alternatives, each tested against the oracle):
  *   "mfma_mode" (default 1): 1 = convolutions on the bf16 matrix pipe -- in fp32 mode (cfg.dtype 0) every fp32 operand is
  *   split exactly into three bf16 terms and a product is six bf16 MFMAs accumulated in fp32 (fp32-equivalent results,
@@ -178,6 +184,13 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   "fuse_first_apply" (1): the first conv's BN-backward transform is applied inside its backward-weights kernel (the
  *   only consumer of that dz) instead of by a bn_bwd_apply pass; bit-identical gradients; oct_unet_debug_activation(0, 1)
  *   then returns the masked gradient g' of block 0, not dz.  0 = separate pass.
+ *   "fuse_bn_apply" (1): every other block's BN-backward transform dz = ga g' + gb z + gd is applied by the consumers of
+ *   dz -- its backward-weights kernel and its backward-data launches -- while they stage g' and z, wherever all of them
+ *   can (the bf16-pipe conv kernels; every MFMA backward-weights kernel); the bn_bwd_apply pass (3 tensor passes per
+ *   block) disappears.  Same two fmas per element as the stand-alone pass: bit-identical gradients.  The block's g buffer
+ *   then keeps g' (oct_unet_debug_layer_fused tells which blocks).  0 = separate pass everywhere.
+ *   "fuse_bn_finalize" (1): BN statistic partials are reduced to the layer's record by the LAST block of the launch that
+ *   produces them (arrival counter; write-through partial rows) instead of by a bn_*_finalize launch.  0 = separate launch.
  *   "dwbt_f32_all" (0): 1 = fp32 mode takes conv_dwbt_k for every thin backward-weights shape (default: where it wins).
  *   "dw_side_stream" (1): backward-weights kernels and the per-step weight preparation run on a low-priority stream
  *   owned by the handle, beside the backward-data chain.  0 = everything on the caller's stream.
@@ -197,13 +210,23 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   and 4-row groups per wave of that kernel; its tile is (4*RPW*NWY) x (32*NWX) pixels. */
 int oct_set_option(const char* name, int value);
 int oct_get_option(const char* name, int* value);
+int oct_unet_get_option(const oct_unet* h, const char* name, int* value);
+/* edit a live handle's copy (between steps).  Everything but "bt_m2" (it shapes the prepared weights); launches never use
+ * more partial-slab rows than were allocated at creation, whatever the block-count knobs say later. */
+int oct_unet_set_option(oct_unet* h, const char* name, int value);
 
 /* ---- introspection for tests: device pointer of a layer's saved pre-BN output / gradient ---- */
 /* which: 0 = z, 1 = g (f32 or bf16 per cfg.dtype; max_batch x out_h x out_w x cout);
- *        2 = the layer's BN record, f32 [6][cout]: a, b (y = relu(a*z + b)), batch/moving mean, rstd, c1, c2 */
+ *        2 = the layer's BN record, f32 [9][cout]: a, b (y = relu(a*z + b)), batch/moving mean, rstd, c1, c2 and the
+ *            BN-backward transform dz = ga g' + gb z + gd as rows ga, gb, gd */
 const void* oct_unet_debug_activation(oct_unet* h, int layer, int which);
+/* 1 if, in the last oct_unet_backward, the layer's BN-backward transform was applied on load by its consumers (its g
+ * buffer still holds the masked gradient g'), 0 if the stand-alone pass turned g into dz in place, -1 on a bad index */
+int oct_unet_debug_layer_fused(const oct_unet* h, int layer);
 
 const char* oct_last_error(void);
+/* "oct_unet_hip <ver> (gfx950) src:<12 hex digits>": the digits are the SHA-256 of the sources the library was built from
+ * (csrc build.sh); the Python binding refuses a library whose stamp differs from the sources beside it */
 const char* oct_version(void);
 
 #ifdef __cplusplus

@@ -78,12 +78,34 @@ SYMBOLS = [
     ("oct_boundary_maps", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("oct_set_option", C.c_int, [C.c_char_p, C.c_int]),
     ("oct_get_option", C.c_int, [C.c_char_p, _P(C.c_int)]),
+    ("oct_unet_get_option", C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_int)]),
+    ("oct_unet_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("oct_unet_debug_activation", C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    ("oct_unet_debug_layer_fused", C.c_int, [C.c_void_p, C.c_int]),
     ("oct_last_error", C.c_char_p, []),
     ("oct_version", C.c_char_p, []),
 ]
 
 _lib = None
+
+
+def source_stamp() -> str:
+    """SHA-256 (12 hex digits) of csrc/*.hip, csrc/*.hpp and include/*.h in build.sh's order, or '' when the sources
+    are not beside the package (an installed copy)."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc, inc = os.path.join(here, "csrc"), os.path.join(here, "..", "include")
+    files = glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(inc, "*.h"))
+    if not files:
+        return ""
+    # build.sh sorts the names as it lists them: '*.hip *.hpp ../../include/*.h' through `sort`
+    rel = sorted((os.path.basename(f) if os.path.dirname(f) == csrc else "../../include/" + os.path.basename(f), f) for f in files)
+    h = hashlib.sha256()
+    for _, f in rel:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
 
 
 def lib() -> C.CDLL:
@@ -102,6 +124,11 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
+        # a stale binary (built from other sources than the ones beside it) must not pass for this tree
+        want, have = source_stamp(), l.oct_version().decode()
+        if want and f"src:{want}" not in have and not os.environ.get("OCT_ALLOW_STALE_LIB"):
+            raise OctError(f"{LIB_PATH} is stale: it reports '{have}' but the sources beside it hash to src:{want}; "
+                           "rebuild with csrc/build.sh (OCT_ALLOW_STALE_LIB=1 overrides)")
         _lib = l
         # tuning knobs for experiments: OCT_OPTIONS="name=value,name=value" (oct_set_option; results do not depend on them)
         for kv in filter(None, os.environ.get("OCT_OPTIONS", "").split(",")):

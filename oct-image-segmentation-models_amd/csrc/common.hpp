@@ -9,13 +9,18 @@ constexpr int kTileX = 32;   // pixel tile of the thread-per-pixel kernels: 32 (
 constexpr int kTileY = 8;
 constexpr int kBlock = 256;  // 4 waves
 
-// per-layer BN device record: 6 arrays of C floats each, in this order
-enum { BN_A = 0, BN_B = 1, BN_MEAN = 2, BN_RSTD = 3, BN_C1 = 4, BN_C2 = 5, BN_ARRAYS = 6 };
+// per-layer BN device record: 9 arrays of C floats each, in this order.  a, b, mean, rstd: forward (y = relu(a z + b));
+// c1, c2: the BN-backward means of g' and g' xhat; ga, gb, gd: the BN-backward transform as two fmas,
+//     dz = gamma rstd (g' - c1 - xhat c2) = ga g' + (gb z + gd),   ga = gamma rstd, gb = -ga rstd c2, gd = -ga c1 - gb mean
+// (bn_bwd_finalize writes c1 .. gd; every consumer of dz -- the stand-alone pass and the stagers of the backward-data /
+// backward-weights kernels that apply it on load -- evaluates exactly fmaf(ga, g', fmaf(gb, z, gd)): same bits everywhere)
+enum { BN_A = 0, BN_B = 1, BN_MEAN = 2, BN_RSTD = 3, BN_C1 = 4, BN_C2 = 5, BN_GA = 6, BN_GB = 7, BN_GD = 8, BN_ARRAYS = 9 };
 
 // input-fetch flags of the conv kernels
 enum { F_U8 = 1, F_AFF = 2, F_TWO = 4, F_UP = 8, F_DROP = 16 };
 
-__constant__ float c_u8_lut[256];  // float32(i / 255.0): bit-identical to the reference's x/255.0 path
+static __constant__ float c_u8_lut[256];  // float32(i / 255.0): bit-identical to the reference's x/255.0 path (static: one
+                                          // copy per translation unit; only oct_unet.hip's is filled and read)
 
 // Counter-based dropout stream: keep(element) = hash(seed, step, idx) >= thresh.  Regenerated in
 // forward, dX and dW, so no mask tensor is ever stored.

@@ -153,54 +153,63 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_flat_k(const PoolBwdArgs A, i
 // ---- BN backward finalize + apply -------------------------------------------------------------------------------
 struct BnBwdFinArgs {
     const float* part; int nblk, C; double count;
-    float* bn; float* dgamma; float* dbeta;
+    float* bn; const float* gamma; float* dgamma; float* dbeta;
 };
 
-__global__ __launch_bounds__(kBlock) void bn_bwd_finalize_k(const BnBwdFinArgs A) {
+// partial sums (s = sum g', q = sum g' xhat) of channel c -> dbeta, dgamma, the record's c1, c2 and the two-fma form of the
+// BN-backward transform (common.hpp); thread 0 of whoever holds the sums (the finalize kernel, or the last block of the
+// producing launch)
+__device__ __forceinline__ void bn_bwd_finalize_write(double s, double q, double count, int C, int c, float* __restrict__ bn,
+                                                      const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta) {
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    const double c1 = s / count, c2 = q / count;
+    const double rstd = (double)bn[BN_RSTD * C + c], mean = (double)bn[BN_MEAN * C + c];
+    const double ga = (double)gamma[c] * rstd, gb = -ga * rstd * c2, gd = -ga * c1 - gb * mean;
+    bn[BN_C1 * C + c] = (float)c1; bn[BN_C2 * C + c] = (float)c2;
+    bn[BN_GA * C + c] = (float)ga; bn[BN_GB * C + c] = (float)gb; bn[BN_GD * C + c] = (float)gd;
+}
+
+static __global__ __launch_bounds__(kBlock) void bn_bwd_finalize_k(const BnBwdFinArgs A) {
     __shared__ double sh[8];
     const int c = blockIdx.x;
     double s, q;
     column_sums_f64(A.part, A.nblk, A.C, c, sh, s, q);
-    if (threadIdx.x == 0) {
-        A.dbeta[c] = (float)s;
-        A.dgamma[c] = (float)q;
-        A.bn[BN_C1 * A.C + c] = (float)(s / A.count);
-        A.bn[BN_C2 * A.C + c] = (float)(q / A.count);
-    }
+    if (threadIdx.x == 0) bn_bwd_finalize_write(s, q, A.count, A.C, c, A.bn, A.gamma, A.dgamma, A.dbeta);
 }
 
-// the BN-backward transform of one element, in ONE place and with its one fma written out, so that the stand-alone pass
-// and the copy fused into conv_dw_first_k produce the same bits
-__device__ __forceinline__ float bn_bwd_apply1(float gm, float rstd, float c1, float c2, float mean, float g, float z) {
-    const float xh = (z - mean) * rstd;                    // (a product that only feeds products / an explicit fma: nothing
-    const float w = fmaf(-xh, c2, g - c1);                 //  is left for the compiler to contract differently per call site)
-    return (gm * rstd) * w;
+// the BN-backward transform of one element: dz = ga g' + (gb z + gd) (record rows BN_GA / BN_GB / BN_GD), written as its
+// two fmas so that the stand-alone pass and every stager that applies it on load produce the same bits
+__device__ __forceinline__ float bn_bwd_apply1(float ga, float gb, float gd, float g, float z) {
+    return fmaf(ga, g, fmaf(gb, z, gd));
+}
+// ... and rounded the way the stand-alone pass would have stored it (bf16 storage), for consumers that never store it
+template <typename AT> __device__ __forceinline__ float dz_as_stored(float v) {
+    if constexpr (sizeof(AT) == 2) return bf2f(f2bf(v)); else return v;
 }
 
-// dz = gamma*rstd*(g' - c1 - xhat*c2), in place over g'
+// dz = ga g' + gb z + gd, in place over g'
 template <typename AT>
 __global__ __launch_bounds__(kBlock) void bn_bwd_apply_k(AT* __restrict__ g, const AT* __restrict__ z,
-                                                        const float* __restrict__ bn, const float* __restrict__ gamma,
-                                                        size_t n4, int C) {
+                                                        const float* __restrict__ bn, size_t n4, int C) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
         const int c = (int)((i * 4) % C);
         const float4 gv = lda4<AT>(g + i * 4), zv = lda4<AT>(z + i * 4);
-        const float4 mean = ld4(bn + BN_MEAN * C + c), rstd = ld4(bn + BN_RSTD * C + c);
-        const float4 c1 = ld4(bn + BN_C1 * C + c), c2 = ld4(bn + BN_C2 * C + c), gm = ld4(gamma + c);
+        const float4 ga = ld4(bn + BN_GA * C + c), gb = ld4(bn + BN_GB * C + c), gd = ld4(bn + BN_GD * C + c);
         float4 o;
-        o.x = bn_bwd_apply1(gm.x, rstd.x, c1.x, c2.x, mean.x, gv.x, zv.x);
-        o.y = bn_bwd_apply1(gm.y, rstd.y, c1.y, c2.y, mean.y, gv.y, zv.y);
-        o.z = bn_bwd_apply1(gm.z, rstd.z, c1.z, c2.z, mean.z, gv.z, zv.z);
-        o.w = bn_bwd_apply1(gm.w, rstd.w, c1.w, c2.w, mean.w, gv.w, zv.w);
+        o.x = bn_bwd_apply1(ga.x, gb.x, gd.x, gv.x, zv.x);
+        o.y = bn_bwd_apply1(ga.y, gb.y, gd.y, gv.y, zv.y);
+        o.z = bn_bwd_apply1(ga.z, gb.z, gd.z, gv.z, zv.z);
+        o.w = bn_bwd_apply1(ga.w, gb.w, gd.w, gv.w, zv.w);
         sta4<AT>(g + i * 4, o);
     }
 }
 
 // bf16 storage, channel count a multiple of 8: 8 elements per thread so that every access is 16 bytes per lane (the
 // 4-element form moves 8 bytes per lane and reaches 4.5 TB/s instead of 6).  Same arithmetic, same operation order.
-__global__ __launch_bounds__(kBlock) void bn_bwd_apply8_bf16_k(bf16_t* __restrict__ g, const bf16_t* __restrict__ z,
-                                                              const float* __restrict__ bn, const float* __restrict__ gamma,
-                                                              size_t n8, int C) {
+static __global__ __launch_bounds__(kBlock) void bn_bwd_apply8_bf16_k(bf16_t* __restrict__ g, const bf16_t* __restrict__ z,
+                                                                     const float* __restrict__ bn, size_t n8, int C) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (size_t)gridDim.x * kBlock) {
         const int c = (int)((i * 8) % C);
         const uint4 gr = *reinterpret_cast<const uint4*>(g + i * 8), zr = *reinterpret_cast<const uint4*>(z + i * 8);
@@ -210,13 +219,12 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply8_bf16_k(bf16_t* __restric
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
             const int cc = c + 4 * hlf;
-            const float4 mean = ld4(bn + BN_MEAN * C + cc), rstd = ld4(bn + BN_RSTD * C + cc);
-            const float4 c1 = ld4(bn + BN_C1 * C + cc), c2 = ld4(bn + BN_C2 * C + cc), gm = ld4(gamma + cc);
+            const float4 ga = ld4(bn + BN_GA * C + cc), gb = ld4(bn + BN_GB * C + cc), gd = ld4(bn + BN_GD * C + cc);
             float4 o;
-            o.x = bn_bwd_apply1(gm.x, rstd.x, c1.x, c2.x, mean.x, gv[hlf].x, zv[hlf].x);
-            o.y = bn_bwd_apply1(gm.y, rstd.y, c1.y, c2.y, mean.y, gv[hlf].y, zv[hlf].y);
-            o.z = bn_bwd_apply1(gm.z, rstd.z, c1.z, c2.z, mean.z, gv[hlf].z, zv[hlf].z);
-            o.w = bn_bwd_apply1(gm.w, rstd.w, c1.w, c2.w, mean.w, gv[hlf].w, zv[hlf].w);
+            o.x = bn_bwd_apply1(ga.x, gb.x, gd.x, gv[hlf].x, zv[hlf].x);
+            o.y = bn_bwd_apply1(ga.y, gb.y, gd.y, gv[hlf].y, zv[hlf].y);
+            o.z = bn_bwd_apply1(ga.z, gb.z, gd.z, gv[hlf].z, zv[hlf].z);
+            o.w = bn_bwd_apply1(ga.w, gb.w, gd.w, gv[hlf].w, zv[hlf].w);
             sta4<bf16_t>(out + 4 * hlf, o);       // the two 8-byte halves of one 16-byte line: merged by the compiler / L2
         }
     }
@@ -338,8 +346,9 @@ struct ConvBwdWArgs {
     const void* x1; const float* ab1; int C1;
     int flags;                                  // F_* (runtime here: staging is outside the FMA loop)
     const void* dz;                             // (B,H,W,Cout), activation storage type
-    const void* zf; const float* bnf; const float* gammaf;   // first layer only, fused BN-backward transform: `dz` is the
-                                                // masked gradient g', dz = gamma*rstd*(g' - c1 - xhat*c2) is formed on load
+    const void* zf; const float* bnf;           // BN-backward transform applied on load (zf != nullptr): `dz` is the masked
+                                                // gradient g' of the layer, zf its raw output z, bnf its BN record; the
+                                                // stager forms dz = ga g' + gb z + gd (common.hpp) instead of reading it
     float* part;                                // [npb][KH*KW*Cin*Cout + Cout]
     int B, H, W, Cin, Cout, tiles_x, tiles, total_tiles, npb;
     DropCfg drop;
@@ -484,9 +493,8 @@ __global__ __launch_bounds__(kBlock) void conv_dw_first_k(const ConvBwdWArgs A, 
                     const float zv[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
 #pragma unroll
                     for (int co = 0; co < 8; ++co) {      // bn_bwd_apply_k's expression; bf16 storage: dz is rounded as it would be stored
-                        const float o = bn_bwd_apply1(A.gammaf[co], A.bnf[BN_RSTD * 8 + co], A.bnf[BN_C1 * 8 + co], A.bnf[BN_C2 * 8 + co],
-                                                      A.bnf[BN_MEAN * 8 + co], d[co], zv[co]);
-                        d[co] = sizeof(AT) == 2 ? bf2f(f2bf(o)) : o;
+                        const float o = bn_bwd_apply1(A.bnf[BN_GA * 8 + co], A.bnf[BN_GB * 8 + co], A.bnf[BN_GD * 8 + co], d[co], zv[co]);
+                        d[co] = dz_as_stored<AT>(o);
                         asm volatile("" : "+v"(d[co]));      // dz is a ROUNDED value (as if stored): its last product must not be
                                                              // contracted into the sums below
                     }
@@ -539,7 +547,7 @@ struct ReduceAllArgs {
     struct Entry { const float* part; float* dw; float* db; int npb, jw; unsigned stride, wsize, blk_start; } L[MAXL];
 };
 
-__global__ __launch_bounds__(kBlock) void reduce_all_k(const ReduceAllArgs A) {
+static __global__ __launch_bounds__(kBlock) void reduce_all_k(const ReduceAllArgs A) {
     __shared__ double sh[kBlock];
     int d = 0;
     while (d + 1 < A.n && blockIdx.x >= A.L[d + 1].blk_start) ++d;
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void reduce_all_k(const ReduceAllArgs A) {
 }
 
 // ---- optimizers (Keras formulations) ----------------------------------------------------
-__global__ __launch_bounds__(kBlock) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+static __global__ __launch_bounds__(kBlock) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                 float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
         const float gi = g[i];
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(kBlock) void adam_k(float* __restrict__ p, const fl
     }
 }
 
-__global__ __launch_bounds__(kBlock) void sgd_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
+static __global__ __launch_bounds__(kBlock) void sgd_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
                                                size_t n, float lr, float momentum) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
         if (mom) { const float vi = momentum * mom[i] - lr * g[i]; mom[i] = vi; p[i] += vi; }

@@ -52,6 +52,23 @@ __device__ __forceinline__ void act8(float (&v)[8], const float (&fa)[8], const 
     }
 }
 
+// BN-backward transform on load (common.hpp): v = g' (8 channels of one pixel), z = the layer's raw output there;
+// v <- dz = ga g' + (gb z + gd) inside the image -- bn_bwd_apply1's two fmas as v_pk_fma_f32 pairs, rounded as the
+// stand-alone pass would have stored it -- and exactly 0 outside (zero padding of dz)
+template <typename AT>
+__device__ __forceinline__ void gb8(float (&v)[8], const float (&z)[8], const float (&ga)[8], const float (&gb)[8], const float (&gd)[8], bool in) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2_hw t = __builtin_elementwise_fma(f32x2_hw{gb[i], gb[i + 1]}, f32x2_hw{z[i], z[i + 1]}, f32x2_hw{gd[i], gd[i + 1]});
+        const f32x2_hw y = __builtin_elementwise_fma(f32x2_hw{ga[i], ga[i + 1]}, f32x2_hw{v[i], v[i + 1]}, t);
+        v[i] = in ? dz_as_stored<AT>(y[0]) : 0.f; v[i + 1] = in ? dz_as_stored<AT>(y[1]) : 0.f;
+    }
+}
+__device__ __forceinline__ void load_gb8(const float* __restrict__ bn, int C, int c, float (&ga)[8], float (&gb)[8], float (&gd)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ga[i] = bn[BN_GA * C + c + i]; gb[i] = bn[BN_GB * C + c + i]; gd[i] = bn[BN_GD * C + c + i]; }
+}
+
 // 8 floats -> NS planes of 8 bf16 (a uint4 each); planes 1 and 2 hold the exact residuals
 template <int NS>
 __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&pl)[NS]) {
@@ -83,7 +100,7 @@ struct WbxDesc {
     unsigned start, count;   // work items (one per (chunk, mblk, ky, kx, m, k-half)) of this entry in the flattened launch
 };
 
-__global__ __launch_bounds__(kBlock) void prep_wbx_k(const WbxDesc* __restrict__ descs, int nd, unsigned total) {
+static __global__ __launch_bounds__(kBlock) void prep_wbx_k(const WbxDesc* __restrict__ descs, int nd, unsigned total) {
     for (unsigned e = blockIdx.x * kBlock + threadIdx.x; e < total; e += gridDim.x * kBlock) {
         int d = 0;
         while (d + 1 < nd && e >= descs[d + 1].start) ++d;
@@ -133,7 +150,9 @@ __host__ inline size_t wbx_bytes(int KH, int Kc, int M, int MB, int NS) {
 // ------------------------------------------------------------------------------------------------------------------
 // NW = waves per block: 4 (one per SIMD) or 8 (two per SIMD: the conversion / LDS phases of one wave run under the MFMAs
 // of its SIMD partner; each wave then owns TH / 8 pixel rows).
-template <int KH, int AMODE, int EPI, int TH, int MB, int NS, bool DROP, int NW, typename AT>
+// GB (backward-data launches): the input x0 is the masked gradient g' of the layer whose dX this is; the BN-backward
+// transform dz = ga g' + gb z + gd (A.gb_z, A.gb_bn; common.hpp) is applied while the tile is staged.
+template <int KH, int AMODE, int EPI, int TH, int MB, int NS, bool DROP, int NW, typename AT, bool GB = false>
 __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
     constexpr int NTHR = 64 * NW;
     constexpr int TW = 32, MTW = MB / 32, NTW = TH / NW, ACC = 16, QUADS = 4, MT = 32;
@@ -149,15 +168,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
     constexpr int SLAB_B = NS * KH * MB * 32;                  // one (chunk, M block, tap row) weight slab
     constexpr int PIECES = SLAB_B / 1024;                      // 1 KiB per LDS-DMA wave instruction
     static_assert(SLAB_B % 1024 == 0, "slab must be a whole number of DMA pieces");
-    constexpr int MAXC = AMODE == A_DOWN2 ? 256 : 512;         // affine rows cached in LDS (K channels; launcher checks)
+    constexpr int MAXC = AMODE == A_DOWN2 ? (GB ? kBxGbDown2MaxC : 256) : 512;   // affine rows cached in LDS (K channels; launcher checks)
     constexpr int EPI_B = EPI == EPI_MASK ? 4 * MB * 4 : MB * 4;
     constexpr int RED_B = NW * 2 * MTW * MT * 4;
     constexpr int SCRATCH_B = (EPI_B + RED_B) > 2 * SLAB_B ? (EPI_B + RED_B) : 2 * SLAB_B;
 
-    __shared__ __attribute__((aligned(1024))) char smem[2 * IN_B + SCRATCH_B + 2 * MAXC * 4];
+    static_assert(!GB || (EPI != EPI_FWD && !DROP), "the BN-backward transform on load belongs to backward-data launches");
+    __shared__ __attribute__((aligned(1024))) char smem[2 * IN_B + SCRATCH_B + (GB ? 3 : 2) * MAXC * 4];
     char* const INs = smem;
     char* const WTs = smem + 2 * IN_B;
-    float* const ABs = reinterpret_cast<float*>(smem + 2 * IN_B + SCRATCH_B);     // [2][MAXC]: a row, b row
+    float* const ABs = reinterpret_cast<float*>(smem + 2 * IN_B + SCRATCH_B);     // [2][MAXC]: a row, b row (GB: ga, gd, gb rows)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -212,9 +232,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
             const float* ab = two ? A.ab1 : A.ab0; const int C = two ? A.C1 : A.C0, cc = two ? c - A.C0 : c;
             av = ab[cc]; bv = ab[C + cc];
         }
+        if constexpr (GB) {
+            const bool ok = c < A.Cin;
+            av = ok ? A.gb_bn[BN_GA * A.Cin + c] : 0.f; bv = ok ? A.gb_bn[BN_GD * A.Cin + c] : 0.f;
+            ABs[2 * MAXC + c] = ok ? A.gb_bn[BN_GB * A.Cin + c] : 0.f;
+        }
         ABs[c] = av; ABs[MAXC + c] = bv;
     }
-    typename Raw4<AT>::type pin[NSLOT][2];
+    typename Raw4<AT>::type pin[NSLOT][2], pz[GB ? NSLOT : 1][2];
     auto load_in = [&](int c0) {
         const int c = c0 + 8 * hh;
         const bool two = (A.flags & F_TWO) && c >= A.C0;
@@ -227,17 +252,26 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
             const AT* p = src + (size_t)(ok ? goff[k] : 0) * C;
             pin[k][0] = ok ? ldraw4<AT>(p) : raw_zero4<AT>();
             pin[k][1] = ok ? ldraw4<AT>(p + 4) : raw_zero4<AT>();
+            if constexpr (GB) {      // same element of the layer's z (same shape as g': one source, no concat)
+                const AT* q = reinterpret_cast<const AT*>(A.gb_z) + c + img * C + (size_t)(ok ? goff[k] : 0) * C;
+                pz[k][0] = ok ? ldraw4<AT>(q) : raw_zero4<AT>();
+                pz[k][1] = ok ? ldraw4<AT>(q + 4) : raw_zero4<AT>();
+            }
         }
     };
     // per-chunk constants of the conversion (set by begin_store, used by store_slot): branch-free so that the
     // conversion of slot k can be scheduled between the MFMAs of a tap
-    float fa[8], fb[8]; bool cok_s = false; int el_c = 0, el_C = 1;
+    float fa[8], fb[8], fz[GB ? 8 : 1]; bool cok_s = false; int el_c = 0, el_C = 1;
     auto begin_store = [&](int c0) {
         const int c = c0 + 8 * hh;
         cok_s = c < A.Cin;
         const float4 a0 = ld4(ABs + c), a1 = ld4(ABs + c + 4), b0 = ld4(ABs + MAXC + c), b1 = ld4(ABs + MAXC + c + 4);
         fa[0] = a0.x; fa[1] = a0.y; fa[2] = a0.z; fa[3] = a0.w; fa[4] = a1.x; fa[5] = a1.y; fa[6] = a1.z; fa[7] = a1.w;
         fb[0] = b0.x; fb[1] = b0.y; fb[2] = b0.z; fb[3] = b0.w; fb[4] = b1.x; fb[5] = b1.y; fb[6] = b1.z; fb[7] = b1.w;
+        if constexpr (GB) {
+            const float4 z0 = ld4(ABs + 2 * MAXC + c), z1 = ld4(ABs + 2 * MAXC + c + 4);
+            fz[0] = z0.x; fz[1] = z0.y; fz[2] = z0.z; fz[3] = z0.w; fz[4] = z1.x; fz[5] = z1.y; fz[6] = z1.z; fz[7] = z1.w;
+        }
         if constexpr (DROP) {
             const bool two = (A.flags & F_TWO) && c >= A.C0;
             el_C = two ? A.C1 : A.C0; el_c = two ? c - A.C0 : c;
@@ -247,10 +281,18 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
         const float4 v0 = widen4(pin[k][0]), v1 = widen4(pin[k][1]);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         const bool in = cok_s && goff[k] >= 0;
+        if constexpr (GB) {
+            const float4 z0 = widen4(pz[k][0]), z1 = widen4(pz[k][1]);
+            const float zv[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {        // zero padding is applied AFTER the activation: out-of-image stays 0
-            const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);     // (act8's med3 / pk_fma form measured slower HERE: the
-            v[i] = in ? y : 0.f;                                      //  compiler's schedule among this kernel's MFMAs changes)
+            for (int i = 0; i < 8; ++i)      // bn_bwd_apply1's two fmas (fa = ga, fz = gb, fb = gd); zero padding of dz
+                v[i] = in ? dz_as_stored<AT>(fmaf(fa[i], v[i], fmaf(fz[i], zv[i], fb[i]))) : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {        // zero padding is applied AFTER the activation: out-of-image stays 0
+                const float y = fmaxf(fmaf(fa[i], v[i], fb[i]), lo);     // (act8's med3 / pk_fma form measured slower HERE: the
+                v[i] = in ? y : 0.f;                                      //  compiler's schedule among this kernel's MFMAs changes)
+            }
         }
         if constexpr (DROP) {
             if (in) {
@@ -351,7 +393,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
                 // trip in front of the step's MFMAs).  Touch the registers first: the wait lands here, where nothing
                 // younger is in flight, and the DMA is issued behind it.
 #pragma unroll
-                for (int k = 0; k < NSLOT; ++k) { touch_raw(pin[k][0]); touch_raw(pin[k][1]); }
+                for (int k = 0; k < NSLOT; ++k) {
+                    touch_raw(pin[k][0]); touch_raw(pin[k][1]);
+                    if constexpr (GB) { touch_raw(pz[k][0]); touch_raw(pz[k][1]); }
+                }
                 begin_store((c + 1) * 16);
             }
             if (!last_row) dma_slab(c, ky + 1, (g + 1) & 1);
@@ -486,7 +531,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
 // ------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int KH, bool UP, int NS, typename AT, bool DROP = false>
+// GB: A.dz is the masked gradient g' and the BN-backward transform is applied while it is staged (A.zf, A.bnf).
+template <int KH, bool UP, int NS, typename AT, bool DROP = false, bool GB = false>
 __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
     constexpr int TH = 4, TW = 32, TAPS = KH * KH;
     constexpr int IH = UP ? TH + 1 : TH + KH - 1, IW = UP ? TW + 1 : TW + KH - 1, PT = UP ? 0 : (KH - 1) / 2;
@@ -512,6 +558,7 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
     const int Cs = two ? A.C1 : A.C0, ccx = two ? cx - A.C0 : cx;
     const AT* __restrict__ xsrc = (two ? reinterpret_cast<const AT*>(A.x1) : reinterpret_cast<const AT*>(A.x0)) + ccx;
     const AT* __restrict__ dsrc = reinterpret_cast<const AT*>(A.dz) + co0 + o8;
+    const AT* __restrict__ zsrc = GB ? reinterpret_cast<const AT*>(A.zf) + co0 + o8 : nullptr;
     const bool aff = (A.flags & F_AFF) != 0;
     const float lo = aff ? 0.f : -3.0e38f;
     float fa[8], fb[8];
@@ -522,13 +569,15 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { fa[i] = ab[ccx + i]; fb[i] = ab[Cs + ccx + i]; }
     }
+    float ga[GB ? 8 : 1], gb[GB ? 8 : 1], gd[GB ? 8 : 1];
+    if constexpr (GB) load_gb8(A.bnf, A.Cout, co0 + o8, ga, gb, gd);
     int xly[NXS], xlx[NXS];
 #pragma unroll
     for (int k = 0; k < NXS; ++k) {
         const int P = (tid >> 2) + k * (kBlock / 4);
         xly[k] = P < NPX ? P / IW : -1000000; xlx[k] = P % IW;      // pad pixels fall outside every image -> zeros
     }
-    struct Regs { typename Raw4<AT>::type x[NXS][2], d[NDS][2]; };
+    struct Regs { typename Raw4<AT>::type x[NXS][2], d[NDS][2], z[GB ? NDS : 1][2]; };
     float bsum[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
@@ -555,8 +604,9 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
             const int P = (tid >> 2) + k * (kBlock / 4);
             int py = g.y0 + P / TW, px = g.x0 + P % TW;
             py = py >= A.H ? A.H - 1 : py; px = px >= A.W ? A.W - 1 : px;
-            const AT* p = dsrc + (((size_t)g.b * A.H + py) * A.W + px) * A.Cout;
-            R.d[k][0] = ldraw4<AT>(p); R.d[k][1] = ldraw4<AT>(p + 4);
+            const size_t e = (((size_t)g.b * A.H + py) * A.W + px) * A.Cout;
+            R.d[k][0] = ldraw4<AT>(dsrc + e); R.d[k][1] = ldraw4<AT>(dsrc + e + 4);
+            if constexpr (GB) { R.z[k][0] = ldraw4<AT>(zsrc + e); R.z[k][1] = ldraw4<AT>(zsrc + e + 4); }
         }
     };
     // `live`: false for the dummy store issued behind the last tile (keeps the loop body branch-free)
@@ -587,8 +637,16 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
             const bool in = live && g.y0 + P / TW < A.H && g.x0 + P % TW < A.W;
             const float4 v0 = widen4(R.d[k][0]), v1 = widen4(R.d[k][1]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if constexpr (GB) {
+                const float4 z0 = widen4(R.z[k][0]), z1 = widen4(R.z[k][1]);
+                const float zv[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+                gb8<AT>(v, zv, ga, gb, gd, in);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[e] = in ? v[e] : 0.f; bsum[e] += v[e]; }
+                for (int e = 0; e < 8; ++e) bsum[e] += v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] = in ? v[e] : 0.f; bsum[e] += v[e]; }
+            }
             uint4 pl[NS];
             split8<NS>(v, pl);
             char* d = smem + buf * BUF_B + NS * XPL + o8 * 2 + P * 64;
@@ -676,7 +734,8 @@ __global__ __launch_bounds__(kBlock, 1) void conv_dwbx_k(const ConvBwdWArgs A) {
             __builtin_amdgcn_sched_group_barrier(0x002, VPS, 0);
             if (((st + 1) * NIT) / STEPS != (st * NIT) / STEPS) {           // a staging item ends behind this step
                 __builtin_amdgcn_sched_group_barrier(0x200, WPS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);         // and its registers are re-loaded for tile t+2
+                if (GB && (st * NIT) / STEPS >= NXS) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);   // and its registers are
+                else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                  // re-loaded for tile t+2
             }
         }
     };
@@ -767,7 +826,7 @@ struct WbtDesc {
     unsigned start, count;               // work items: (K-group, row, K-slice)
 };
 
-__global__ __launch_bounds__(kBlock) void prep_wbt_k(const WbtDesc* __restrict__ descs, int nd, unsigned total) {
+static __global__ __launch_bounds__(kBlock) void prep_wbt_k(const WbtDesc* __restrict__ descs, int nd, unsigned total) {
     for (unsigned e = blockIdx.x * kBlock + threadIdx.x; e < total; e += gridDim.x * kBlock) {
         int d = 0;
         while (d + 1 < nd && e >= descs[d + 1].start) ++d;
@@ -802,8 +861,11 @@ __global__ __launch_bounds__(kBlock) void prep_wbt_k(const WbtDesc* __restrict__
 __host__ inline int wbt_groups(int KH, int CT, bool m2 = false) { const int tpm = 32 / CT; return (KH * (m2 ? KH + 1 : KH) + tpm - 1) / tpm; }
 __host__ inline size_t wbt_bytes(int KH, int CT, int NS, bool m2 = false) { return (size_t)wbt_groups(KH, CT, m2) * NS * 16 * 32 * 2; }
 
-template <int KH, int AMODE, int EPI, int CT, int NS, typename AT, bool M2 = false>
+// GB (backward-data launches): x0 is the masked gradient g' of the layer; dz = ga g' + gb z + gd is formed while the tile is
+// staged (A.gb_z, A.gb_bn; common.hpp) -- the stand-alone bn_bwd_apply pass over g' is gone.
+template <int KH, int AMODE, int EPI, int CT, int NS, typename AT, bool M2 = false, bool GB = false>
 __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void conv_bt_k(const IgemmArgs A) {
+    static_assert(!GB || EPI != EPI_FWD, "the BN-backward transform on load belongs to backward-data launches");
     static_assert(!M2 || ((CT == 8 || CT == 16) && AMODE != A_DOWN2), "two-pixel form: 8 or 16 K channels, unit-stride or upsampled input");
     constexpr int TH = 8, TW = 32, TAPS = KH * (M2 ? KH + 1 : KH), TPM = 32 / CT, NG = (TAPS + TPM - 1) / TPM, OCT = CT / 8;
     constexpr int KW = M2 ? KH + 1 : KH;                          // taps per kernel row of the (extended) window
@@ -866,6 +928,10 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
 #pragma unroll
         for (int i = 0; i < 8; ++i) { fa[i] = ab[ccx + i]; fb[i] = ab[Cs + ccx + i]; }
     }
+    float fz[GB ? 8 : 1];
+    if constexpr (GB) load_gb8(A.gb_bn, A.Cin, c8, fa, fz, fb);     // fa = ga, fz = gb, fb = gd (one source: no concat)
+    // z of the layer sits at the same element offsets as g' (both are carved from the handle's workspace)
+    const ptrdiff_t zdelta = GB ? reinterpret_cast<const AT*>(A.gb_z) - reinterpret_cast<const AT*>(A.x0) : 0;
     int sly[NSLOT], slx[NSLOT], sdst[NSLOT];
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
@@ -873,7 +939,7 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
         sly[k] = P < NPIX ? P / IW : -1000000; slx[k] = P % IW;                 // pad pixels fall outside every image
         sdst[k] = lds_off(P, o);
     }
-    struct RegSet { typename Raw4<AT>::type v[NSLOT][2]; };
+    struct RegSet { typename Raw4<AT>::type v[NSLOT][2], z[GB ? NSLOT : 1][2]; };
     auto origin = [&](const TileOrg& t, int& iy0, int& ix0) {
         const int y0 = t.ty * TH, x0 = t.tx * TW;
         iy0 = AMODE == A_NORMAL ? y0 - (KH - 1) / 2 : (AMODE == A_UPF ? y0 / 2 : 2 * y0 - 1);
@@ -908,13 +974,18 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
     };
     auto load_item = [&](int k, const AT* ib, RegSet& RS) {
         RS.v[k][0] = ldraw4<AT>(ib + aoff[k]); RS.v[k][1] = ldraw4<AT>(ib + aoff[k] + 4);
+        if constexpr (GB) { RS.z[k][0] = ldraw4<AT>(ib + zdelta + aoff[k]); RS.z[k][1] = ldraw4<AT>(ib + zdelta + aoff[k] + 4); }
     };
     auto store_item = [&](int k, int iy0, int ix0, int buf, const RegSet& RS) {
         const float4 v0 = widen4(RS.v[k][0]), v1 = widen4(RS.v[k][1]);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         const int gy = iy0 + sly[k], gx = ix0 + slx[k];
         const bool in = gy >= 0 && gy < A.Hi && gx >= 0 && gx < A.Wi;
-        act8(v, fa, fb, lo, in);
+        if constexpr (GB) {
+            const float4 z0 = widen4(RS.z[k][0]), z1 = widen4(RS.z[k][1]);
+            const float zv[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+            gb8<AT>(v, zv, fa, fz, fb, in);
+        } else act8(v, fa, fb, lo, in);
         uint4 pl[NS];
         split8<NS>(v, pl);
         char* d = smem + buf * IN_B + sdst[k];
@@ -1036,7 +1107,7 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
             // whole conversion in front of the MFMAs): per step the fragments two steps ahead, the step's MFMAs, a share
             // of the conversion VALU in their shadow, and behind an item its LDS writes and the two loads that refill it
             constexpr int NPROD = NS == 3 ? 6 : 1;
-            constexpr int VPS = (NSLOT * (NS == 3 ? 60 : 36) + STEPS - 1) / STEPS;
+            constexpr int VPS = (NSLOT * ((NS == 3 ? 60 : 36) + (GB ? (sizeof(AT) == 2 ? 16 : 4) : 0)) + STEPS - 1) / STEPS;
             __builtin_amdgcn_sched_group_barrier(0x100, STEPS > 1 ? 2 * NS : NS, 0);
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
@@ -1048,7 +1119,7 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
                 for (int k = 0; k < NSLOT; ++k) item = item || (k * STEPS) / NSLOT == st;
                 if (item) {
                     __builtin_amdgcn_sched_group_barrier(0x200, NS, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, GB ? 4 : 2, 0);
                 }
             }
         }
@@ -1122,7 +1193,8 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
 // branch-free (loads clamped, one tile ahead in registers, LDS images double buffered) so it is scheduled among the
 // MFMAs; fixed-order 4-wave sum, ONE partial slab per block.  grid (npb, 1, 1).
 // ------------------------------------------------------------------------------------------------------------------
-template <int KH, bool UP, int CI, int CO, int NS, typename AT, bool DROP = false>
+// GB: A.dz is the masked gradient g' and the BN-backward transform is applied while it is staged (A.zf, A.bnf).
+template <int KH, bool UP, int CI, int CO, int NS, typename AT, bool DROP = false, bool GB = false>
 __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(const ConvBwdWArgs A) {
     constexpr int TH = 4, TW = 32, TAPS = KH * KH;
     constexpr int IH = UP ? TH + 1 : TH + KH - 1, IW = UP ? TW + 1 : TW + KH - 1, PT = UP ? 0 : (KH - 1) / 2;
@@ -1149,6 +1221,7 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
     const AT* __restrict__ xsrc = (two ? reinterpret_cast<const AT*>(A.x1) : reinterpret_cast<const AT*>(A.x0)) + ccx;
     const int od = tid % OD;
     const AT* __restrict__ dsrc = reinterpret_cast<const AT*>(A.dz) + 8 * od;
+    const AT* __restrict__ zsrc = GB ? reinterpret_cast<const AT*>(A.zf) + 8 * od : nullptr;
     const bool aff = (A.flags & F_AFF) != 0;
     const float lo = aff ? 0.f : -3.0e38f;
     float fa[8], fb[8];
@@ -1159,13 +1232,15 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
 #pragma unroll
         for (int i = 0; i < 8; ++i) { fa[i] = ab[ccx + i]; fb[i] = ab[Cs + ccx + i]; }
     }
+    float ga[GB ? 8 : 1], gb[GB ? 8 : 1], gd[GB ? 8 : 1];
+    if constexpr (GB) load_gb8(A.bnf, A.Cout, 8 * od, ga, gb, gd);
     int xly[NXS], xlx[NXS];
 #pragma unroll
     for (int k = 0; k < NXS; ++k) {
         const int P = tid / OX + k * PPX;
         xly[k] = P < NPX ? P / IW : -1000000; xlx[k] = P % IW;               // pad pixels fall outside every image -> zeros
     }
-    struct Regs { typename Raw4<AT>::type x[NXS][2], d[NDS][2]; };
+    struct Regs { typename Raw4<AT>::type x[NXS][2], d[NDS][2], z[GB ? NDS : 1][2]; };
     float bsum[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
@@ -1192,8 +1267,9 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
             const int P = tid / OD + k * PPD;
             int py = g.y0 + P / TW, px = g.x0 + P % TW;
             py = py >= A.H ? A.H - 1 : py; px = px >= A.W ? A.W - 1 : px;
-            const AT* p = dsrc + (((size_t)g.b * A.H + py) * A.W + px) * A.Cout;
-            R.d[k][0] = ldraw4<AT>(p); R.d[k][1] = ldraw4<AT>(p + 4);
+            const size_t e = (((size_t)g.b * A.H + py) * A.W + px) * A.Cout;
+            R.d[k][0] = ldraw4<AT>(dsrc + e); R.d[k][1] = ldraw4<AT>(dsrc + e + 4);
+            if constexpr (GB) { R.z[k][0] = ldraw4<AT>(zsrc + e); R.z[k][1] = ldraw4<AT>(zsrc + e + 4); }
         }
     };
     auto store_item = [&](int i, const Geo& g, const Regs& R, int buf, bool live) {
@@ -1223,8 +1299,16 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
             const bool in = live && P < NPD && g.y0 + P / TW < A.H && g.x0 + P % TW < A.W;
             const float4 v0 = widen4(R.d[k][0]), v1 = widen4(R.d[k][1]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if constexpr (GB) {
+                const float4 z0 = widen4(R.z[k][0]), z1 = widen4(R.z[k][1]);
+                const float zv[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+                gb8<AT>(v, zv, ga, gb, gd, in);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[e] = in ? v[e] : 0.f; bsum[e] += v[e]; }
+                for (int e = 0; e < 8; ++e) bsum[e] += v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] = in ? v[e] : 0.f; bsum[e] += v[e]; }
+            }
             uint4 pl[NS];
             split8<NS>(v, pl);
             char* d = smem + buf * BUF_B + NS * XPL + od * 16 + P * DPB;
@@ -1304,7 +1388,7 @@ __global__ __launch_bounds__(kBlock, (CI + CO >= 48) ? 1 : 2) void conv_dwbt_k(c
             __builtin_amdgcn_sched_group_barrier(0x002, VPS, 0);
             if (((mt + 1) * NIT) / MTILES != (mt * NIT) / MTILES) {
                 __builtin_amdgcn_sched_group_barrier(0x200, NS * IPS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 2 * IPS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, (GB ? 4 : 2) * IPS, 0);
             }
         }
     };

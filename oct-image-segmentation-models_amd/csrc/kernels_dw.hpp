@@ -18,13 +18,14 @@ namespace oct {
 // is a multiple of CIC/4 and COC/4), so its source tensor (concat aware), BN affine and LDS column never change; per
 // slot only the packed local pixel (ly, lx) is kept.  Per tile: one wave-uniform base pointer, and interior tiles skip
 // every bounds test.
-template <int CIC, int COC, int IH, int IW, bool UP, int KH, int TH, typename AT, int XSTRIDE = CIC>
+// GB: `dz` is the masked gradient g'; the BN-backward transform dz = ga g' + gb z + gd is applied while the tile is stored.
+template <int CIC, int COC, int IH, int IW, bool UP, int KH, int TH, typename AT, int XSTRIDE = CIC, bool GB = false>
 struct TileStager {
     static constexpr int QX = CIC / 4, PPX = kBlock / QX, NPX = IH * IW, NX = (NPX + PPX - 1) / PPX;   // X tile
     static constexpr int QD = COC / 4, PPD = kBlock / QD, NPD = TH * 32, ND = (NPD + PPD - 1) / PPD;   // dz tile
-    typename Raw4<AT>::type xr[NX], dr[ND];     // raw prefetch registers (widened in store())
-    float4 fa, fb;
-    const AT* __restrict__ xsrc; const AT* __restrict__ dsrc;
+    typename Raw4<AT>::type xr[NX], dr[ND], zr[GB ? ND : 1];     // raw prefetch registers (widened in store())
+    float4 fa, fb, ga, gb, gd;
+    const AT* __restrict__ xsrc; const AT* __restrict__ dsrc; const AT* __restrict__ zsrc;
     int lxy[NX], dxy[ND];
     int Cs, cc, xq4, dq4; bool cok, dok;
 
@@ -40,6 +41,9 @@ struct TileStager {
         const int dc = co0 + 4 * (tid % QD);
         dok = dc < A.Cout; dq4 = 4 * (tid % QD);
         dsrc = reinterpret_cast<const AT*>(A.dz) + dc;
+        zsrc = GB ? reinterpret_cast<const AT*>(A.zf) + dc : nullptr;
+        ga = gb = gd = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (GB && dok) { ga = ld4(A.bnf + BN_GA * A.Cout + dc); gb = ld4(A.bnf + BN_GB * A.Cout + dc); gd = ld4(A.bnf + BN_GD * A.Cout + dc); }
 #pragma unroll
         for (int k = 0; k < ND; ++k) { const int p = tid / QD + k * PPD; dxy[k] = p < NPD ? ((p / 32) << 8) | (p % 32) : -1; }
     }
@@ -59,7 +63,8 @@ struct TileStager {
             if (!interior) ok = ok && (unsigned)(iy0 + ly) < (unsigned)Hs && (unsigned)(ix0 + lx) < (unsigned)Ws;
             xr[k] = ok ? ldraw4<AT>(tb + (ly * Ws + lx) * Cs) : raw_zero4<AT>();
         }
-        const AT* __restrict__ db = dsrc + (((long long)b * A.H + y0) * A.W + x0) * A.Cout;
+        const long long doff = (((long long)b * A.H + y0) * A.W + x0) * A.Cout;
+        const AT* __restrict__ db = dsrc + doff;
         const bool dint = y0 + TH <= A.H && x0 + 32 <= A.W;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
@@ -67,6 +72,7 @@ struct TileStager {
             bool ok = dok && dxy[k] >= 0;
             if (!dint) ok = ok && y0 + py < A.H && x0 + px < A.W;
             dr[k] = ok ? ldraw4<AT>(db + (py * A.W + px) * A.Cout) : raw_zero4<AT>();
+            if constexpr (GB) zr[k] = ok ? ldraw4<AT>(zsrc + doff + (py * A.W + px) * A.Cout) : raw_zero4<AT>();
         }
     }
     // write the loaded tile to LDS, applying the input transform; accumulates dz column sums (bias gradient)
@@ -98,7 +104,16 @@ struct TileStager {
         for (int k = 0; k < ND; ++k) {
             if (dxy[k] < 0) continue;
             const int py = dxy[k] >> 8, px = dxy[k] & 255;
-            const float4 d = widen4(dr[k]);
+            float4 d = widen4(dr[k]);
+            if constexpr (GB) {       // (elements past the image / channel range: g' = z = 0 and ga = gb = gd = 0 -> 0 only if
+                                      //  the coefficients are zero too, so out-of-image pixels are forced to zero explicitly)
+                const float4 z = widen4(zr[k]);
+                const bool in = dok && y0 + py < A.H && x0 + px < A.W;
+                d.x = in ? dz_as_stored<AT>(bn_bwd_apply1(ga.x, gb.x, gd.x, d.x, z.x)) : 0.f;
+                d.y = in ? dz_as_stored<AT>(bn_bwd_apply1(ga.y, gb.y, gd.y, d.y, z.y)) : 0.f;
+                d.z = in ? dz_as_stored<AT>(bn_bwd_apply1(ga.z, gb.z, gd.z, d.z, z.z)) : 0.f;
+                d.w = in ? dz_as_stored<AT>(bn_bwd_apply1(ga.w, gb.w, gd.w, d.w, z.w)) : 0.f;
+            }
             st4(Ds + (py * 32 + px) * COC + dq4, d);
             bsum.x += d.x; bsum.y += d.y; bsum.z += d.z; bsum.w += d.w;
         }
@@ -125,7 +140,7 @@ __device__ __forceinline__ void bias_reduce(const ConvBwdWArgs& A, float* scratc
 // Every wave owns ALL M tiles for a quarter of the tile's pixel rows; 4-wave sum through LDS at the end.
 // grid (npb, ceil(Cin/CIC), ceil(Cout/16))
 // ---------------------------------------------------------------------------------------------------------------
-template <int KH, int CIC, bool UP, typename AT>
+template <int KH, int CIC, bool UP, typename AT, bool GB = false>
 __global__ __launch_bounds__(kBlock, 3) void conv_dw16_k(const ConvBwdWArgs A) {   // 3 waves/SIMD: <= 168 VGPRs
     constexpr int TH = 8, TW = 32, TAPS = KH * KH, MROWS = TAPS * CIC, MTILES = (MROWS + 15) / 16;
     constexpr int IH = UP ? TH / 2 + 1 : TH + KH - 1, IW = UP ? TW / 2 + 1 : TW + KH - 1;
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(kBlock, 3) void conv_dw16_k(const ConvBwdWArgs A) {
     for (int mt = 0; mt < MTILES; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    TileStager<CIC, 16, IH, IW, UP, KH, TH, AT> st;
+    TileStager<CIC, 16, IH, IW, UP, KH, TH, AT, CIC, GB> st;
     st.init(A, ci0, co0);
     auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
         b = tl / A.tiles; const int tile = tl % A.tiles;
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(kBlock, 3) void conv_dw16_k(const ConvBwdWArgs A) {
 // Every wave owns all M tiles for a quarter of the tile's pixel rows; 4-wave sum through LDS at the end.
 // grid (npb, ceil(Cin/CIC), 1); requires Cout == 8, KH == 3, not an up-conv.
 // ---------------------------------------------------------------------------------------------------------------
-template <int CIC, typename AT>
+template <int CIC, typename AT, bool GB = false>
 __global__ __launch_bounds__(kBlock) void conv_dwpair8_k(const ConvBwdWArgs A) {
     constexpr int KH = 3, TH = 8, TW = 32, MROWS = 12 * CIC, MTILES = MROWS / 16, XST = CIC == 16 ? 20 : CIC;
     constexpr int IH = TH + 2, IW = TW + 2;
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void conv_dwpair8_k(const ConvBwdWArgs A) {
     for (int mt = 0; mt < MTILES; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    TileStager<CIC, 8, IH, IW, false, KH, TH, AT, XST> st;
+    TileStager<CIC, 8, IH, IW, false, KH, TH, AT, XST, GB> st;
     st.init(A, ci0, 0);
     auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
         b = tl / A.tiles; const int tile = tl % A.tiles;
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void conv_dwpair8_k(const ConvBwdWArgs A) {
 // The (ci-tile, tap) units are dealt round-robin to the 4 waves; every wave sweeps all pixels of the tile for
 // its own units, so no cross-wave reduction is needed.   grid (npb, Cin/CIC, Cout/32)
 // ---------------------------------------------------------------------------------------------------------------
-template <int KH, int CIC, bool UP, int TH, typename AT>
+template <int KH, int CIC, bool UP, int TH, typename AT, bool GB = false>
 __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
     constexpr int TW = 32, COC = 32, TAPS = KH * KH, MTB = CIC / 32, UNITS = MTB * TAPS, UPW = (UNITS + 3) / 4;
     constexpr int IH = UP ? TH / 2 + 1 : TH + KH - 1, IW = UP ? TW / 2 + 1 : TW + KH - 1;
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void conv_dw32_k(const ConvBwdWArgs A) {
         xb[k] = Xs + (UP ? ((kk + ukx[k]) >> 1) : uky[k] * IW + ukx[k] + kk) * CIC + umt[k] * 32 + i;
     const float* const db = Ds + kk * COC + i;
 
-    TileStager<CIC, COC, IH, IW, UP, KH, TH, AT> st;
+    TileStager<CIC, COC, IH, IW, UP, KH, TH, AT, CIC, GB> st;
     st.init(A, ci0, co0);
     auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
         b = tl / A.tiles; const int tile = tl % A.tiles;

@@ -198,7 +198,7 @@ struct BnFinArgs {
     float eps, momentum; int unbiased;
 };
 
-__global__ __launch_bounds__(kBlock) void bn_fwd_finalize_k(const BnFinArgs A) {
+static __global__ __launch_bounds__(kBlock) void bn_fwd_finalize_k(const BnFinArgs A) {
     __shared__ double sh[8];
     const int c = blockIdx.x;
     double s, q;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void bn_fwd_finalize_k(const BnFinArgs A) {
 }
 
 // inference: (a, b) from the moving statistics, one thread per channel of one layer
-__global__ void bn_infer_coeffs_k(const float* gamma, const float* beta, const float* mm, const float* mv,
+static __global__ void bn_infer_coeffs_k(const float* gamma, const float* beta, const float* mm, const float* mv,
                                   float* bn, int C, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -238,7 +238,7 @@ struct BnInferAll {
     int n;
     struct Entry { const float* gamma; const float* beta; const float* mm; const float* mv; float* bn; int C; } L[MAXL];
 };
-__global__ void bn_infer_all_k(const BnInferAll A, float eps) {
+static __global__ void bn_infer_all_k(const BnInferAll A, float eps) {
     const BnInferAll::Entry E = A.L[blockIdx.x];
     for (int c = threadIdx.x; c < E.C; c += blockDim.x) {
         const float rstd = 1.f / sqrtf(E.mv[c] + eps), a = E.gamma[c] * rstd;
@@ -385,7 +385,7 @@ struct DiceFinArgs {
     float focal_w;
 };
 
-__global__ __launch_bounds__(kBlock) void dice_finalize_k(const DiceFinArgs A) {
+static __global__ __launch_bounds__(kBlock) void dice_finalize_k(const DiceFinArgs A) {
     __shared__ double sh[8][kBlock];
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // score_macro, coef_macro, I, T, P, Ih, Ph (micro sums), focal sum
     const int n = A.B * A.C;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void dice_finalize_k(const DiceFinArgs A) {
 //   cur = [label == k],  g = 2*max(+-gradient_rows(cur), 0)  (np.gradient: central differences, one-sided at the
 //   edges),  out = uint8(255 * max(g[r] - g[(r+1) mod H], 0))   -- exact in small integers.
 // labels (B,H,W) u8 -> maps (B, C-1, H, W) u8.  One thread per (b, r, c); adjacent threads walk adjacent columns.
-__global__ __launch_bounds__(kBlock) void boundary_maps_k(const unsigned char* __restrict__ lab, unsigned char* __restrict__ out,
+static __global__ __launch_bounds__(kBlock) void boundary_maps_k(const unsigned char* __restrict__ lab, unsigned char* __restrict__ out,
                                                          int B, int H, int W, int C, int bg_ilm, int bg_csi) {
     const size_t n = (size_t)B * H * W;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void boundary_maps_k(const unsigned char* _
 }
 
 // dropout keep-mask dump for parity tests
-__global__ void dropout_mask_k(unsigned char* out, size_t n, DropCfg d) {
+static __global__ void dropout_mask_k(unsigned char* out, size_t n, DropCfg d) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = drop_hash(d.seed, d.step, (uint32_t)i) >= d.thresh ? 1 : 0;
 }

@@ -21,6 +21,8 @@
 namespace oct {
 
 enum { A_NORMAL = 0, A_UPF = 1, A_DOWN2 = 2 };
+constexpr int kBxGbDown2MaxC = 192;   // conv_bx_k, stride-2 gather with the BN-backward transform on load: K channels whose three
+                                      // coefficient rows still fit beside the LDS images (the host falls back to the separate pass)
 enum { EPI_FWD = 0, EPI_RAW = 1, EPI_MASK = 2 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -45,6 +47,13 @@ struct IgemmArgs {
                                                  // in prep_wbx_k layout, and the total M the layout was built for
     int bt_m2;                                   // ... prepared in the two-pixel form (8 output channels x 2 adjacent pixels = 16 rows)
     const void* wbt;                             // thin bf16-pipe kernel: prep_wbt_k slice for rows m_off .. m_off + 15
+    const void* gb_z; const float* gb_bn;        // backward-data on the bf16-pipe kernels, BN-backward transform on load: x0 is
+                                                 // the masked gradient g' of the layer, gb_z its raw output z, gb_bn its BN
+                                                 // record (Cin channels): the stager forms dz = ga g' + gb z + gd (common.hpp)
+    unsigned* fin_counter;                       // statistics finalized in this launch (last block): arrival counter, or nullptr
+    const float* fin_gamma; const float* fin_beta; float* fin_bn; float* fin_mm; float* fin_mv;   // EPI_FWD: BnFinArgs fields
+    float* fin_dgamma; float* fin_dbeta;         // EPI_MASK: BnBwdFinArgs fields (fin_bn = producer's record, fin_gamma its gamma)
+    double fin_count; float fin_eps, fin_momentum; int fin_unbiased;
 };
 
 template <int SHAPE> struct MfmaShape;
@@ -683,7 +692,7 @@ struct WtDesc {
     unsigned start, count;       // element range of this layer in the flattened launch
 };
 
-__global__ __launch_bounds__(kBlock) void prep_wt_k(const WtDesc* __restrict__ descs, int nd, unsigned total) {
+static __global__ __launch_bounds__(kBlock) void prep_wt_k(const WtDesc* __restrict__ descs, int nd, unsigned total) {
     for (unsigned e = blockIdx.x * kBlock + threadIdx.x; e < total; e += gridDim.x * kBlock) {
         int d = 0;
         while (d + 1 < nd && e >= descs[d + 1].start) ++d;

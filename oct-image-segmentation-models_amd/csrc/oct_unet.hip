@@ -9,75 +9,46 @@
 #include <vector>
 
 #include "../../include/oct_unet.h"
-#include "common.hpp"
+#include "host.hpp"
 #include "kernels_bwd.hpp"
 #include "kernels_fwd.hpp"
 #include "kernels_igemm.hpp"
-#include "kernels_dw.hpp"
-#include "kernels_thin.hpp"
-#include "kernels_pair.hpp"
 #include "kernels_bx.hpp"
 
 using namespace oct;
+using namespace octh;
 
-namespace {
+#ifndef OCT_SRC_HASH
+#define OCT_SRC_HASH "unstamped"     // build.sh passes the SHA-256 (12 hex digits) of csrc/*.hip, csrc/*.hpp, include/*.h
+#endif
 
-thread_local std::string g_err;
-int g_thin_min_tiles = 2048;      // pixel tiles from which 8-channel layers use the VALU thin kernel
-int g_dw32_blocks = 512, g_dw16_blocks = 768;   // target resident blocks of a backward-weights launch (wide / thin kernels)
-int g_igemm_p_blocks = 1280;      // persistent igemm grid
-int g_igemm_min_blocks = 512;     // a layer takes the taller pixel tile only if that still yields this many blocks
-int g_dwpair8 = 1;                // 3x3 layers with 8 output channels: pixel-pair backward-weights kernel (0 = padded 16-column kernel)
-int g_pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW: waves per block (rows x cols) and 4-row groups per wave
-int g_pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
-int g_dw_side_stream = 1;          // backward-weights kernels on the handle's side stream beside the backward-data chain
-int g_bx_waves = 8;                // waves per block of conv_bx_k where the tile has >= 8 rows: 8 = two per SIMD, 4 = one per SIMD
-int g_fuse_first_apply = 1;        // the first conv's BN-backward transform is applied inside its backward-weights kernel
-int g_bt_m2 = 1;                   // conv_bt_k: 8-output-channel launches in the two-pixel form (fixed per engine at create)
-int g_dwbt_f32_all = 0;            // 1: fp32 mode also takes conv_dwbt_k for every thin shape (tests exercise all instantiations)
-int g_bt_blocks_per_cu = 0;        // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows: 3 / 2 / 1 at 8 / 16 / 32 input channels)
-int g_dwbx_blocks = 256;           // target grid of a bf16-pipe backward-weights launch (1 block per CU: the kernel needs most of the LDS)
-int g_bx_min_blocks = 256;         // a bf16-pipe launch takes the taller pixel tile only if that still yields this many blocks
-int g_mfma_mode = 1;               // 1: convs with >= 32 output channels run on the bf16 MFMA pipe (kernels_bx.hpp: 6 split products
-                                  //    in fp32 mode, 1 in bf16 mode); 0: the fp32-pipe kernels everywhere
-int g_focal_clip_mod = 0;          // focal loss: 1 = the (1-p)^gamma modulation sees the clipped p too (see include/oct_unet.h)
-int g_persist_min_tiles = 2048;   // pixel tiles from which thin single-chunk convs use the persistent pipelined kernel
+namespace octh {
+Options g_opt;
+thread_local Profiler* t_prof = nullptr;
+namespace { thread_local std::string g_err; }
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
-#define HIP_OK(expr)                                                                               \
-    do {                                                                                           \
-        hipError_t e__ = (expr);                                                                   \
-        if (e__ != hipSuccess) return fail(-5, std::string(#expr) + ": " + hipGetErrorString(e__)); \
-    } while (0)
+// the conv launchers live in their own translation units (tu_conv_*.hip): one explicit instantiation each
+extern template int launch_igemm<3, A_NORMAL, EPI_FWD>(const IgemmArgs&, const LaunchCtx&, int*);
+extern template int launch_igemm<2, A_UPF, EPI_FWD>(const IgemmArgs&, const LaunchCtx&, int*);
+extern template int launch_igemm<3, A_NORMAL, EPI_MASK>(const IgemmArgs&, const LaunchCtx&, int*);
+extern template int launch_igemm<3, A_NORMAL, EPI_RAW>(const IgemmArgs&, const LaunchCtx&, int*);
+extern template int launch_igemm<3, A_DOWN2, EPI_MASK>(const IgemmArgs&, const LaunchCtx&, int*);
 
-// ---- per-launch HIP-event profiler (off by default; bench.py turns it on for a few untimed steps) ---------
-struct ProfRec { std::string kernel, layer; double flops, bytes; hipEvent_t e0, e1; };
-struct Profiler {
-    bool on = false;
-    std::vector<ProfRec> recs;
-    std::vector<hipEvent_t> pool;
-    hipEvent_t get() {
-        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
-        hipEvent_t e; (void)hipEventCreate(&e); return e;
-    }
-};
-thread_local Profiler* t_prof = nullptr;
+// which kernel family launch_igemm (launch_conv.hpp) hands a launch to
+ConvRoute conv_route(const IgemmArgs& a, int amode, const Options& o) {
+    const bool octets_ok = !(a.flags & F_TWO) || a.C0 % 8 == 0;    // staging moves 8-channel octets: one source tensor each
+    if (o.mfma_mode && a.wbt && a.Mout <= 16 && a.Mout % 4 == 0 && bt_k_ok(a.Cin) && !(a.flags & F_DROP) && octets_ok &&
+        (amode != A_DOWN2 || a.Cin == 8))
+        return ROUTE_BT;
+    if (o.mfma_mode && a.wbx && a.Mout % 32 == 0 && a.Cin % 8 == 0 && a.m_off % bx_mb(a.Mout) == 0 && octets_ok &&
+        a.Cin <= (amode == A_DOWN2 ? 256 : 512))       // the kernel caches the affine rows of its K channels in LDS
+        return ROUTE_BX;
+    return ROUTE_F32;
+}
+}  // namespace octh
 
-// RAII: records an event pair around the launch(es) issued in its scope, on the launch stream itself
-struct ProfScope {
-    Profiler* p; hipStream_t s; size_t idx;
-    ProfScope(hipStream_t st, const char* kernel, const char* layer, double flops, double bytes) : p(t_prof), s(st), idx(0) {
-        if (!p || !p->on) { p = nullptr; return; }
-        ProfRec r{kernel, layer, flops, bytes, p->get(), p->get()};
-        (void)hipEventRecord(r.e0, s);
-        idx = p->recs.size(); p->recs.push_back(r);
-    }
-    ~ProfScope() { if (p) (void)hipEventRecord(p->recs[idx].e1, s); }
-};
-
-// run a launch statement with `AT` bound to the activation storage type
-#define AT_DISPATCH(bf, ...) do { if (bf) { using AT = bf16_t; __VA_ARGS__; } else { using AT = float; __VA_ARGS__; } } while (0)
-#define AT_NAME(bf) ((bf) ? "unsigned short" : "float")
+namespace {
 
 enum Src { SRC_INPUT, SRC_PREV, SRC_POOL, SRC_UP, SRC_CONCAT, SRC_HEAD };
 
@@ -94,6 +65,7 @@ struct Layer {
     bf16_t* wbx_f = nullptr; bf16_t* wbx_b = nullptr;   // split weights for the bf16-pipe kernels (forward / backward-data)
     bool bt_m2_f = false, bt_m2_b = false;                // thin kernel: this layer's forward / backward-data launches use the two-pixel form
     bf16_t* wbt_f = nullptr; bf16_t* wbt_b = nullptr;   // ... for the thin bf16-pipe kernel (16-row slices; backward: cin / Cg slices)
+    bool g_masked = false;   // last backward: the BN-backward transform was applied on load, `g` still holds the masked gradient g'
 };
 
 struct Plan {
@@ -174,26 +146,23 @@ Plan build_plan(const oct_unet_cfg& c) {
     return pl;
 }
 
-inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int tiles_of(int H, int W) { return cdiv(H, kTileY) * cdiv(W, kTileX); }
 inline int chunk_of(int c) { return c % 16 == 0 ? 16 : (c % 8 == 0 ? 8 : 4); }   // channel chunk per thread
 
 // ---- bf16-pipe kernel eligibility (kernels_bx.hpp): forward needs >= 32 output channels, backward-data >= 32 channels
 // per launch (a concat's dX is two launches of cin/2 channels each); K channels in multiples of 8, <= 512 ----
-inline int bx_mb(int M) { return M % 64 == 0 ? 64 : 32; }
 inline bool bx_fwd_ok(const Layer& l) { return l.src != SRC_INPUT && l.has_bn && l.cin % 8 == 0 && l.cin <= 512 && l.cout % 32 == 0; }
 inline int bx_bwd_cg(const Layer& l) { return l.src == SRC_CONCAT ? l.cin / 2 : l.cin; }
 inline bool bx_bwd_ok(const Layer& l) { return l.src != SRC_INPUT && l.has_bn && l.cout % 8 == 0 && l.cout <= 512 && bx_bwd_cg(l) % 32 == 0; }
 
 // thin bf16-pipe kernel (conv_bt_k): <= 16 output channels per launch, K channels exactly 8, 16 or 32
-inline bool bt_k_ok(int k) { return k == 8 || k == 16 || k == 32; }
 inline bool bt_fwd_ok(const Layer& l) { return l.src != SRC_INPUT && l.has_bn && l.cout <= 16 && l.cout % 4 == 0 && bt_k_ok(l.cin); }
 inline bool bt_bwd_ok(const Layer& l) { const int cg = bx_bwd_cg(l); return l.src != SRC_INPUT && l.has_bn && cg <= 16 && cg % 4 == 0 && bt_k_ok(l.cout); }
 
 // two-pixel form of the thin kernel: exactly 8 output channels per launch, 8 or 16 K channels, not the stride-2 gather
-inline bool bt_m2_fwd(const Layer& l) { return g_bt_m2 && bt_fwd_ok(l) && l.cout == 8 && (l.cin == 8 || l.cin == 16); }
-inline bool bt_m2_bwd(const Layer& l) { return g_bt_m2 && bt_bwd_ok(l) && l.src != SRC_UP && bx_bwd_cg(l) == 8 && (l.cout == 8 || l.cout == 16); }
+inline bool bt_m2_fwd(const Layer& l, const Options& o) { return o.bt_m2 && bt_fwd_ok(l) && l.cout == 8 && (l.cin == 8 || l.cin == 16); }
+inline bool bt_m2_bwd(const Layer& l, const Options& o) { return o.bt_m2 && bt_bwd_ok(l) && l.src != SRC_UP && bx_bwd_cg(l) == 8 && (l.cout == 8 || l.cout == 16); }
 
 // thin backward-weights on the bf16 pipe (conv_dwbt_k): the instantiated (cin, cout) pairs
 inline bool dwbt_ok(const Layer& l) {
@@ -206,21 +175,20 @@ inline bool dwbt_ok(const Layer& l) {
 }
 
 // dW plan: which kernel handles a layer, its channel chunking, pixel-tile height and pixel-block count
-struct DwPlan { int kind;  /* 0 = VALU (1-channel input / head), 16, 32, 33 = bf16 pipe (conv_dwbx_k) */ int cic, coc, th, chunks, npb, tiles; };
-DwPlan dw_plan(const Layer& l, int B, int mfma_mode, int bf16) {
+DwPlan dw_plan(const Layer& l, int B, int mfma_mode, int bf16, const Options& o) {
     DwPlan p{};
     if (mfma_mode && l.src != SRC_INPUT && l.kh != 1 && l.cin % 32 == 0 && l.cout % 32 == 0) {
         // wide layers on the bf16 pipe: one block per (32 ci, 32 co) pair and pixel slice, ~1 block per CU in total
         p.kind = 33; p.cic = 32; p.coc = 32; p.th = 4;
         p.chunks = (l.cin / 32) * (l.cout / 32);
         p.tiles = cdiv(l.H, p.th) * cdiv(l.W, kTileX);
-        p.npb = std::max(1, std::min(B * p.tiles, cdiv(g_dwbx_blocks, p.chunks)));
+        p.npb = std::max(1, std::min(B * p.tiles, cdiv(o.dwbx_blocks, p.chunks)));
         return p;
     }
     // fp32 mode: the three-term split of both operands makes conv_dwbt_k VALU-bound; measured per shape (B=32 256x512,
     // us, fp32-pipe kernel vs this one): 8->8 89 / 100, up-convs 98 / 113 and 55 / 66 stay on the fp32 pipe; 16->8 149 /
     // 143, 32->16 103 / 92, 8->16 39 / 35, 16->16 59 / 48, 16->32 come here.  bf16 mode (one rounding, one product): all.
-    if (mfma_mode && dwbt_ok(l) && (bf16 || g_dwbt_f32_all || (l.src != SRC_UP && !(l.cin == 8 && l.cout == 8)))) {
+    if (mfma_mode && dwbt_ok(l) && (bf16 || o.dwbt_f32_all || (l.src != SRC_UP && !(l.cin == 8 && l.cout == 8)))) {
         // thin layers on the bf16 pipe (conv_dwbt_k): one block holds all channels; 1 or 2 blocks per CU (LDS images)
         p.kind = 34; p.cic = l.cin; p.coc = l.cout; p.th = 4; p.chunks = 1;
         p.tiles = cdiv(l.H, p.th) * cdiv(l.W, kTileX);
@@ -241,7 +209,7 @@ DwPlan dw_plan(const Layer& l, int B, int mfma_mode, int bf16) {
     const int total = B * p.tiles;
     // one full round of resident blocks (no half-empty tail round): the wide kernel fits 2 blocks per CU (registers),
     // for the thin one 768 blocks measured best
-    const int target = p.kind == 32 ? g_dw32_blocks : g_dw16_blocks;
+    const int target = p.kind == 32 ? o.dw32_blocks : o.dw16_blocks;
     p.npb = std::max(1, std::min(total, cdiv(target, p.chunks)));
     return p;
 }
@@ -250,6 +218,7 @@ DwPlan dw_plan(const Layer& l, int B, int mfma_mode, int bf16) {
 
 struct oct_unet {
     oct_unet_cfg cfg;
+    Options opt;                           // snapshot of the process-wide defaults at creation (host.hpp)
     Plan plan;
     float* params; float* grads; float* state;
     std::vector<void*> pooled, gpooled;    // per encoder level (activation storage type)
@@ -274,7 +243,7 @@ struct oct_unet {
 namespace {
 
 // Carve the workspace; with base == nullptr only sizes are computed.  Returns total bytes.
-size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
+size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base, const Options& o) {
     size_t off = 0;
     auto take = [&](size_t bytes) -> char* { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
     const size_t B = (size_t)c.max_batch, esz = c.dtype ? 2 : 4;   // bytes per stored activation element
@@ -288,7 +257,7 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
         const int ns = c.dtype ? 1 : 3;
         bf16_t* wf = bx_fwd_ok(l) ? (bf16_t*)take(wbx_bytes(l.kh, l.cin, l.cout, bx_mb(l.cout), ns)) : nullptr;
         bf16_t* wb = (c.training && bx_bwd_ok(l)) ? (bf16_t*)take(wbx_bytes(3, l.cout, l.cin, bx_mb(bx_bwd_cg(l)), ns)) : nullptr;
-        const bool m2f = bt_m2_fwd(l), m2b = bt_m2_bwd(l);
+        const bool m2f = bt_m2_fwd(l, o), m2b = bt_m2_bwd(l, o);
         bf16_t* tf = bt_fwd_ok(l) ? (bf16_t*)take(wbt_bytes(l.kh, l.cin, ns, m2f)) : nullptr;
         bf16_t* tb = (c.training && bt_bwd_ok(l)) ? (bf16_t*)take(wbt_bytes(3, l.cout, ns, m2b) * (l.cin / bx_bwd_cg(l))) : nullptr;
         if (base) { l.bt_m2_f = m2f; l.bt_m2_b = m2b; }
@@ -298,7 +267,7 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base) {
         if (c.training) {
             const size_t wsz = (size_t)l.kh * l.kw * l.cin * l.cout + l.cout;
             const size_t rows = l.src == SRC_HEAD ? (size_t)(2048 + c.max_batch)
-                                                  : (size_t)std::max(dw_plan(l, c.max_batch, 0, 0).npb, std::max(dw_plan(l, c.max_batch, 1, 1).npb, dw_plan(l, c.max_batch, 1, 0).npb));
+                                                  : (size_t)std::max(dw_plan(l, c.max_batch, 0, 0, o).npb, std::max(dw_plan(l, c.max_batch, 1, 1, o).npb, dw_plan(l, c.max_batch, 1, 0, o).npb));
             float* dwp = (float*)take(rows * wsz * 4);
             if (base) { l.dwp = dwp; l.dw_rows = (int)rows; }
             dw_max = 0;
@@ -370,199 +339,6 @@ SrcDesc src_of(const oct_unet* h, int li, const void* x_in, int x_is_u8) {
     return d;
 }
 
-// ---- MFMA implicit-GEMM launcher: picks the MFMA shape from the channel count and the pixel tile from the grid size ----
-template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN>
-int launch_igemm_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH);
-    dim3 grid(a.tiles, cdiv(a.Mout, MB), B), block(kBlock);
-    char nm[64]; snprintf(nm, sizeof nm, "conv_igemm_k<%d,%d,%d,%d,%d,%d,%d,%s>", SHAPE, KH, AMODE, EPI, TH, MB, WN, AT_NAME(a.act_bf16));
-    ProfScope ps(s, nm, layer, flops, bytes);
-    AT_DISPATCH(a.act_bf16, conv_igemm_k<SHAPE, KH, AMODE, EPI, TH, MB, WN, AT><<<grid, block, 0, s>>>(a));
-    HIP_OK(hipGetLastError());
-    *rows = B * a.tiles;   // one statistic partial row per (image, pixel tile)
-    return 0;
-}
-
-// persistent pipelined variant (single K chunk): returns the number of statistic partial rows (= blocks along x)
-template <int SHAPE, int KH, int AMODE, int EPI, int TH, int MB, int WN, int KCP>
-int launch_igemm_p(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH); a.total_tiles = B * a.tiles;
-    const int nblk = std::min(a.total_tiles, g_igemm_p_blocks);    // ~5 resident blocks per CU
-    dim3 grid(nblk, cdiv(a.Mout, MB), 1), block(kBlock);
-    char nm[64]; snprintf(nm, sizeof nm, "conv_igemm_p_k<%d,%d,%d,%d,%d,%d,%d,%d,%s>", SHAPE, KH, AMODE, EPI, TH, MB, WN, KCP, AT_NAME(a.act_bf16));
-    ProfScope ps(s, nm, layer, flops, bytes);
-    AT_DISPATCH(a.act_bf16, conv_igemm_p_k<SHAPE, KH, AMODE, EPI, TH, MB, WN, KCP, AT><<<grid, block, 0, s>>>(a));
-    HIP_OK(hipGetLastError());
-    *rows = nblk;       // one statistic partial row per block
-    return 0;
-}
-
-#ifndef PAIR_DEPTH
-#define PAIR_DEPTH 1     // register prefetch depth of the 8-input-channel pair kernel (tiles in flight beyond the one in LDS)
-#endif
-// pixel-pair MFMA kernel for 3x3 layers with 8 output channels (see kernels_pair.hpp)
-template <int EPI, int CMAX, int NWY, int NWX, int RPW>
-int launch_pair8_geo(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    constexpr int NT = 64 * NWY * NWX, DEPTH = PAIR_DEPTH;
-    a.tiles_x = cdiv(a.Wo, 32 * NWX); a.tiles = a.tiles_x * cdiv(a.Ho, 4 * RPW * NWY); a.total_tiles = B * a.tiles;
-    static int occ[2] = {0, 0};
-    const int bf = a.act_bf16 ? 1 : 0;
-    if (!occ[bf]) {
-        int nb = 0;
-        AT_DISPATCH(bf, if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_pair8_k<EPI, CMAX, DEPTH, NWY, NWX, RPW, AT>, NT, 0) != hipSuccess) nb = 0);
-        occ[bf] = nb < 1 ? 2 : nb;
-    }
-    const int nblk = std::min(a.total_tiles, occ[bf] * 256);
-    char nm[80]; snprintf(nm, sizeof nm, "conv_pair8_k<%d,%d,%d,%d,%d,%d,%s>", EPI, CMAX, DEPTH, NWY, NWX, RPW, AT_NAME(a.act_bf16));
-    ProfScope ps(s, nm, layer, flops, bytes);
-    AT_DISPATCH(bf, conv_pair8_k<EPI, CMAX, DEPTH, NWY, NWX, RPW, AT><<<nblk, NT, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
-    HIP_OK(hipGetLastError());
-    *rows = nblk;
-    return 0;
-}
-template <int EPI>
-int launch_pair8(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    const int geo = g_pair_geo;    // NWY*100 + NWX*10 + RPW
-    if (a.Cin <= 8) {
-        if (geo == 111) return launch_pair8_geo<EPI, 8, 1, 1, 1>(a, B, s, layer, flops, bytes, rows);
-        return launch_pair8_geo<EPI, 8, 2, 2, 1>(a, B, s, layer, flops, bytes, rows);
-    }
-    if (geo == 111) return launch_pair8_geo<EPI, 16, 1, 1, 1>(a, B, s, layer, flops, bytes, rows);
-    return launch_pair8_geo<EPI, 16, 2, 2, 1>(a, B, s, layer, flops, bytes, rows);
-}
-
-// VALU kernel for 8-output-channel layers (see kernels_thin.hpp)
-template <int KH, int AMODE, int EPI>
-int launch_thin8(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    a.tiles_x = cdiv(a.Wo, 64); a.tiles = a.tiles_x * cdiv(a.Ho, 8); a.total_tiles = B * a.tiles;
-    const int nblk = std::min(a.total_tiles, 1536);
-    char nm[64]; snprintf(nm, sizeof nm, "conv_thin8_k<%d,%d,%d,%d,%s>", KH, AMODE, EPI, a.Cin <= 8 ? 8 : 16, AT_NAME(a.act_bf16));
-    ProfScope ps(s, nm, layer, flops, bytes);
-    if (a.Cin <= 8) AT_DISPATCH(a.act_bf16, conv_thin8_k<KH, AMODE, EPI, 8, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
-    else AT_DISPATCH(a.act_bf16, conv_thin8_k<KH, AMODE, EPI, 16, AT><<<nblk, kBlock, 0, s>>>(a, a.w, reinterpret_cast<AT*>(a.out)));
-    HIP_OK(hipGetLastError());
-    *rows = nblk;
-    return 0;
-}
-
-// ---- bf16-pipe implicit GEMM (kernels_bx.hpp): NS = 3 split products in fp32 mode, 1 in bf16 mode ----
-template <int KH, int AMODE, int EPI, int TH, int MB, int NW>
-int launch_bx_nw(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH);
-    dim3 grid(a.tiles, cdiv(a.Mout, MB), B), block(64 * NW);
-    char nm[64]; snprintf(nm, sizeof nm, "conv_bx_k<%d,%d,%d,%d,%d,%d,%d,%s>", KH, AMODE, EPI, TH, MB, a.act_bf16 ? 1 : 3, NW, AT_NAME(a.act_bf16));
-    ProfScope ps(s, nm, layer, flops, bytes);
-    if constexpr (AMODE == A_UPF && EPI == EPI_FWD) {
-        if (a.flags & F_DROP) {
-            if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, true, NW, bf16_t><<<grid, block, 0, s>>>(a);
-            else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, true, NW, float><<<grid, block, 0, s>>>(a);
-            HIP_OK(hipGetLastError());
-            *rows = B * a.tiles;
-            return 0;
-        }
-    }
-    if (a.flags & F_DROP) return fail(-3, "conv_bx_k: dropout on the input is only built for the up-conv forward");
-    if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, false, NW, bf16_t><<<grid, block, 0, s>>>(a);
-    else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, false, NW, float><<<grid, block, 0, s>>>(a);
-    HIP_OK(hipGetLastError());
-    *rows = B * a.tiles;
-    return 0;
-}
-template <int KH, int AMODE, int EPI, int TH, int MB>
-int launch_bx_geo(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    if constexpr (TH % 8 == 0) {
-        if (g_bx_waves == 8) return launch_bx_nw<KH, AMODE, EPI, TH, MB, 8>(a, B, s, layer, flops, bytes, rows);
-    }
-    return launch_bx_nw<KH, AMODE, EPI, TH, MB, 4>(a, B, s, layer, flops, bytes, rows);
-}
-template <int KH, int AMODE, int EPI>
-int launch_bx(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    auto blocks = [&](int th, int mb) { return (long)B * cdiv(a.Ho, th) * cdiv(a.Wo, 32) * cdiv(a.Mout, mb); };
-    if constexpr (AMODE == A_DOWN2) {      // 2x-strided input tile: only the 4-row tile fits the LDS double buffer
-        if (a.Mout % 64 == 0) return launch_bx_geo<KH, AMODE, EPI, 4, 64>(a, B, s, layer, flops, bytes, rows);
-        return launch_bx_geo<KH, AMODE, EPI, 4, 32>(a, B, s, layer, flops, bytes, rows);
-    } else {
-        if (a.Mout % 64 == 0) {
-            if (blocks(8, 64) >= g_bx_min_blocks) return launch_bx_geo<KH, AMODE, EPI, 8, 64>(a, B, s, layer, flops, bytes, rows);
-            return launch_bx_geo<KH, AMODE, EPI, 4, 64>(a, B, s, layer, flops, bytes, rows);
-        }
-        if (blocks(16, 32) >= g_bx_min_blocks) return launch_bx_geo<KH, AMODE, EPI, 16, 32>(a, B, s, layer, flops, bytes, rows);
-        return launch_bx_geo<KH, AMODE, EPI, 8, 32>(a, B, s, layer, flops, bytes, rows);
-    }
-}
-
-// ---- thin bf16-pipe kernel (conv_bt_k): persistent, weights in registers ----
-template <int KH, int AMODE, int EPI>
-int launch_bt(IgemmArgs a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, 8); a.total_tiles = B * a.tiles;
-    const int per_cu = a.Cin == 32 ? 1 : (a.Cin == 16 ? 2 : 3);     // what the LDS images and registers of the instantiation allow
-    const int nblk = std::min(a.total_tiles, g_bt_blocks_per_cu > 0 ? 256 * std::min(g_bt_blocks_per_cu, per_cu) : 256 * per_cu);
-    const int bf = a.act_bf16 ? 1 : 0;
-    const bool m2 = a.bt_m2 && a.Mout == 8 && AMODE != A_DOWN2 && (a.Cin == 8 || a.Cin == 16);
-    char nm[64]; snprintf(nm, sizeof nm, "conv_bt_k<%d,%d,%d,%d,%d,%s%s>", KH, AMODE, EPI, a.Cin, bf ? 1 : 3, AT_NAME(bf), m2 ? ",2px" : "");
-    ProfScope ps(s, nm, layer, flops, bytes);
-    if (a.bt_m2 && !m2) return fail(-3, "conv_bt_k: weights were prepared in the two-pixel form for a launch that cannot use it");
-#define BT_CASE(CT) case CT: if (bf) conv_bt_k<KH, AMODE, EPI, CT, 1, bf16_t><<<nblk, kBlock, 0, s>>>(a); \
-                             else conv_bt_k<KH, AMODE, EPI, CT, 3, float><<<nblk, kBlock, 0, s>>>(a); break;
-#define BT_M2(CT) case CT: if (bf) conv_bt_k<KH, AMODE, EPI, CT, 1, bf16_t, true><<<nblk, kBlock, 0, s>>>(a); \
-                           else conv_bt_k<KH, AMODE, EPI, CT, 3, float, true><<<nblk, kBlock, 0, s>>>(a); break;
-    if constexpr (AMODE != A_DOWN2) {
-        if (m2) {
-            switch (a.Cin) { BT_M2(8) BT_M2(16) default: break; }
-            HIP_OK(hipGetLastError());
-            *rows = nblk;
-            return 0;
-        }
-    }
-    if constexpr (AMODE == A_DOWN2) {     // the 2x-strided input tile only fits the LDS double buffer at 8 channels
-        switch (a.Cin) { BT_CASE(8) default: return fail(-3, "conv_bt_k: stride-2 gather needs 8 K channels"); }
-    } else {
-        switch (a.Cin) { BT_CASE(8) BT_CASE(16) BT_CASE(32) default: return fail(-3, "conv_bt_k: K channels must be 8, 16 or 32"); }
-    }
-#undef BT_CASE
-#undef BT_M2
-    HIP_OK(hipGetLastError());
-    *rows = nblk;
-    return 0;
-}
-
-template <int KH, int AMODE, int EPI>
-int launch_igemm(const IgemmArgs& a, int B, hipStream_t s, const char* layer, double flops, double bytes, int* rows) {
-    const bool octets_ok = !(a.flags & F_TWO) || a.C0 % 8 == 0;    // staging moves 8-channel octets: one source tensor each
-    if (g_mfma_mode && a.wbt && a.Mout <= 16 && a.Mout % 4 == 0 && bt_k_ok(a.Cin) && !(a.flags & F_DROP) && octets_ok &&
-        (AMODE != A_DOWN2 || a.Cin == 8))
-        return launch_bt<KH, AMODE, EPI>(a, B, s, layer, flops, bytes, rows);
-    if (g_mfma_mode && a.wbx && a.Mout % 32 == 0 && a.Cin % 8 == 0 && a.m_off % bx_mb(a.Mout) == 0 && octets_ok &&
-        a.Cin <= (AMODE == A_DOWN2 ? 256 : 512))       // the kernel caches the affine rows of its K channels in LDS
-        return launch_bx<KH, AMODE, EPI>(a, B, s, layer, flops, bytes, rows);
-    auto blocks = [&](int th, int mb) { return (long)B * cdiv(a.Ho, th) * cdiv(a.Wo, 32) * cdiv(a.Mout, mb); };
-    if constexpr (AMODE == A_NORMAL && KH == 3) {
-        // 8 output channels, 3x3: two adjacent pixels share one 16-row MFMA tile (75 % useful instead of 50 %)
-        if (a.Mout == 8 && a.Cin <= 16 && blocks(8, 16) >= g_pair_min_tiles)
-            return launch_pair8<EPI>(a, B, s, layer, flops, bytes, rows);
-    }
-    if constexpr (AMODE != A_DOWN2) {
-        // 8 output channels: a 16-row MFMA tile would be half padding -> VALU kernel (same f32 peak, no padding)
-        if (a.Mout == 8 && a.Cin <= 16 && blocks(8, 16) >= g_thin_min_tiles)
-            return launch_thin8<KH, AMODE, EPI>(a, B, s, layer, flops, bytes, rows);
-        // thin single-chunk layers with plenty of pixel tiles: persistent software-pipelined kernel
-        if (a.Cin <= 16 && a.Mout <= 16 && blocks(8, 16) >= g_persist_min_tiles) {
-            if (a.Cin <= 8) return launch_igemm_p<16, KH, AMODE, EPI, 8, 16, 4, 8>(a, B, s, layer, flops, bytes, rows);
-            return launch_igemm_p<16, KH, AMODE, EPI, 8, 16, 4, 16>(a, B, s, layer, flops, bytes, rows);
-        }
-    }
-    if (a.Mout <= 16) {
-        if (blocks(8, 16) >= g_igemm_min_blocks) return launch_igemm_geo<16, KH, AMODE, EPI, 8, 16, 4>(a, B, s, layer, flops, bytes, rows);
-        return launch_igemm_geo<16, KH, AMODE, EPI, 4, 16, 4>(a, B, s, layer, flops, bytes, rows);
-    }
-    if (a.Mout <= 32) {
-        if (blocks(8, 32) >= g_igemm_min_blocks) return launch_igemm_geo<32, KH, AMODE, EPI, 8, 32, 4>(a, B, s, layer, flops, bytes, rows);
-        return launch_igemm_geo<32, KH, AMODE, EPI, 4, 32, 4>(a, B, s, layer, flops, bytes, rows);
-    }
-    if (blocks(4, 64) >= g_igemm_min_blocks) return launch_igemm_geo<32, KH, AMODE, EPI, 4, 64, 4>(a, B, s, layer, flops, bytes, rows);
-    return launch_igemm_geo<32, KH, AMODE, EPI, 2, 64, 2>(a, B, s, layer, flops, bytes, rows);
-}
-
 // algorithmic bytes of a conv's logical input, read once: low-res tensor for an up-conv, both
 // halves of a concat, the pooled tensor after a pool, 1 B/px for a u8 image
 double in_bytes(const Layer& l, int B, int x_is_u8, int es = 4) {
@@ -596,8 +372,9 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
         g.Ho = l.H; g.Wo = l.W; g.Hi = l.src == SRC_UP ? l.H / 2 : l.H; g.Wi = l.src == SRC_UP ? l.W / 2 : l.W;
         g.part = a.part; g.drop = a.drop; g.act_bf16 = h->cfg.dtype;
         g.wbx = l.wbx_f; g.wbx_M = l.cout; g.wbt = l.wbt_f; g.bt_m2 = l.bt_m2_f;
-        rc = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows)
-                             : launch_igemm<3, A_NORMAL, EPI_FWD>(g, B, s, l.name, fl, by, &stat_rows);
+        const LaunchCtx lc{&h->opt, B, s, l.name, fl, by};
+        rc = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, lc, &stat_rows)
+                             : launch_igemm<3, A_NORMAL, EPI_FWD>(g, lc, &stat_rows);
     } else if (l.src == SRC_INPUT && l.cin == 1 && l.cout == 8 && l.kh == 3) {   // the real first layer: persistent streaming kernel
         const int tx = cdiv(l.W, 128), tiles = tx * cdiv(l.H, 8), total = B * tiles;
         const int grid = std::min(total, 2048);      // <= B*ceil(H/2)*ceil(W/32) statistic rows guaranteed by carve()
@@ -691,15 +468,15 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
     const int nl = (int)pl.L.size();
     // this step's weights, split / rounded into bf16 MFMA operand order (one launch per kernel family).  In a training
     // step they run on the side stream under the first layer (which does not use them).
-    const bool fside = training && g_dw_side_stream && h->side && !(t_prof && t_prof->on);
+    const bool fside = training && h->opt.dw_side_stream && h->side && !(t_prof && t_prof->on);
     hipStream_t ps_ = fside ? h->side : s;
     if (fside) { HIP_OK(hipEventRecord(h->fork_ev[0], s)); HIP_OK(hipStreamWaitEvent(h->side, h->fork_ev[0], 0)); }
-    if (g_mfma_mode && h->n_wbx_f) {
+    if (h->opt.mfma_mode && h->n_wbx_f) {
         ProfScope ps(ps_, "prep_wbx_k", "all", 0, (double)h->wbx_f_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
         prep_wbx_k<<<std::min<unsigned>((h->wbx_f_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, ps_>>>(h->wbx_descs, h->n_wbx_f, h->wbx_f_total);
         HIP_OK(hipGetLastError());
     }
-    if (g_mfma_mode && h->n_wbt_f) {
+    if (h->opt.mfma_mode && h->n_wbt_f) {
         ProfScope ps(ps_, "prep_wbt_k", "all", 0, (double)h->wbt_f_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
         prep_wbt_k<<<std::min<unsigned>((h->wbt_f_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, ps_>>>(h->wbt_descs, h->n_wbt_f, h->wbt_f_total);
         HIP_OK(hipGetLastError());
@@ -739,7 +516,7 @@ int forward_impl(oct_unet* h, const void* x, int x_is_u8, int B, int training, c
     a.z = last.z; a.ab = last.bn; a.w = h->params + hd.w_off; a.bias = h->params + hd.b_off;
     a.probs = io ? io->probs : nullptr; a.argmax = io ? io->argmax : nullptr; a.labels = io ? io->labels : nullptr;
     a.dice_part = h->dice_part; a.HW = hd.H * hd.W; a.nblk = head_nblk(a.HW, B); a.act_bf16 = h->cfg.dtype;
-    a.focal_on = h->focal_w > 0.f; a.focal_gamma = h->focal_gamma; a.focal_cw = h->focal_cw; a.focal_clip_mod = g_focal_clip_mod;
+    a.focal_on = h->focal_w > 0.f; a.focal_gamma = h->focal_gamma; a.focal_cw = h->focal_cw; a.focal_clip_mod = h->opt.focal_clip_mod;
     const int rc = DISPATCH_C(launch_head_fwd, h->cfg.n_cls, a, hd.cin, B, s);
     if (rc) return rc;
     h->last_B = B; h->last_training = training; h->have_dice = a.labels != nullptr;
@@ -794,10 +571,13 @@ inline bool first_dw_streams(const Layer& l) {
     return l.src == SRC_INPUT && l.cin == 1 && l.cout == 8 && l.kh == 3 && l.has_bn && !l.drop_in;
 }
 
+// backward-weights of block li.  fused_apply: `dz` is the masked gradient g' and the kernel applies the BN-backward
+// transform of the block on load (every kernel but the generic VALU one of odd first layers can)
 int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const void* dz, int B, hipStream_t s, bool fused_apply = false) {
     const Layer& l = h->plan.L[li];
+    const Options& o = h->opt;
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
-    DwPlan p = dw_plan(l, B, g_mfma_mode, h->cfg.dtype);
+    DwPlan p = dw_plan(l, B, o.mfma_mode, h->cfg.dtype, o);
     p.npb = std::min(p.npb, l.dw_rows);
     ConvBwdWArgs a{};
     a.x0 = sd.x0; a.ab0 = sd.ab0; a.C0 = sd.C0; a.x1 = sd.x1; a.ab1 = sd.ab1; a.C1 = sd.C1;
@@ -806,10 +586,12 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
     a.B = B; a.H = l.H; a.W = l.W; a.Cin = l.cin; a.Cout = l.cout;
     a.tiles_x = cdiv(l.W, kTileX); a.tiles = p.tiles; a.total_tiles = B * a.tiles; a.npb = p.npb;
     a.drop = make_drop(h); a.act_bf16 = h->cfg.dtype;
+    if (fused_apply) { a.zf = l.z; a.bnf = l.bn; }
     const double px = (double)B * l.H * l.W, fl = 2.0 * l.kh * l.kw * l.cin * l.cout * px;
     const int es = h->cfg.dtype ? 2 : 4;
-    const double by = in_bytes(l, B, x_is_u8, es) + px * l.cout * es;   // conv input once + dz once
+    const double by = in_bytes(l, B, x_is_u8, es) + px * l.cout * es * (fused_apply ? 2 : 1);   // conv input once + dz once (fused: g' and z)
     const bool up = l.src == SRC_UP;
+    const LaunchCtx lc{&o, B, s, l.name, fl, by};
     int rc = 0;
     if (p.kind == 0 && l.cin == 1 && l.cout == 8 && l.kh == 3 && !(a.flags & (F_AFF | F_DROP | F_TWO | F_UP))) {
         // the real first layer: streaming reduction kernel (kernels_bwd.hpp)
@@ -817,79 +599,36 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
         const int grid = std::min(total, a.npb);
         a.npb = grid;
         const int bf = a.act_bf16;
-        ProfScope ps(s, bf ? "conv_dw_first_k<unsigned short>" : "conv_dw_first_k<float>", l.name, fl, by + (fused_apply ? px * l.cout * es : 0));
-        if (fused_apply) {
-            a.zf = l.z; a.bnf = l.bn; a.gammaf = h->params + l.gamma_off;
-            AT_DISPATCH(bf, (conv_dw_first_k<AT, true><<<grid, kBlock, 0, s>>>(a, tx, tiles, total)));
-        } else {
-            AT_DISPATCH(bf, (conv_dw_first_k<AT, false><<<grid, kBlock, 0, s>>>(a, tx, tiles, total)));
-        }
+        ProfScope ps(s, bf ? "conv_dw_first_k<unsigned short>" : "conv_dw_first_k<float>", l.name, fl, by);
+        if (fused_apply) AT_DISPATCH(bf, (conv_dw_first_k<AT, true><<<grid, kBlock, 0, s>>>(a, tx, tiles, total)));
+        else AT_DISPATCH(bf, (conv_dw_first_k<AT, false><<<grid, kBlock, 0, s>>>(a, tx, tiles, total)));
         HIP_OK(hipGetLastError());
-    } else if (fused_apply) {
-        return fail(-3, "conv_backward_w: fused BN-backward apply is only built into the streaming first-layer kernel");
     } else if (p.kind == 0) {
+        if (fused_apply) return fail(-3, "conv_backward_w: the generic first-layer kernel does not apply the BN-backward transform");
         rc = launch_dw<3>(a, p.cic, p.coc, s, l.name, fl, by);   // other 1-channel / odd-channel first layers
-    } else if (p.kind == 34) {
-        const int bf = a.act_bf16 ? 1 : 0;
-        char nm[64]; snprintf(nm, sizeof nm, "conv_dwbt_k<%d,%s,%d,%d,%d,%s>", l.kh, up ? "true" : "false", l.cin, l.cout, bf ? 1 : 3, AT_NAME(bf));
-        ProfScope ps(s, nm, l.name, fl, by);
-        const bool dr = (a.flags & F_DROP) != 0;          // dropout on the input: only the up-conv behind the bottleneck
-        if (dr && !up) return fail(-3, "conv_dwbt_k: dropout on the input is only built for the up-conv");
-#define DWBT_D(KHV, UPV, CI, CO, DR) { \
-            if (bf) conv_dwbt_k<KHV, UPV, CI, CO, 1, bf16_t, DR><<<p.npb, kBlock, 0, s>>>(a); \
-            else conv_dwbt_k<KHV, UPV, CI, CO, 3, float, DR><<<p.npb, kBlock, 0, s>>>(a); }
-#define DWBT(KHV, UPV, CI, CO) if (l.cin == CI && l.cout == CO) { if (UPV && dr) DWBT_D(KHV, UPV, CI, CO, UPV) else DWBT_D(KHV, UPV, CI, CO, false) }
-        if (up) { DWBT(2, true, 16, 8) else DWBT(2, true, 32, 16) else return fail(-3, "conv_dwbt_k: up-conv shape not instantiated"); }
-        else { DWBT(3, false, 8, 8) else DWBT(3, false, 8, 16) else DWBT(3, false, 16, 8) else DWBT(3, false, 16, 16)
-               else DWBT(3, false, 16, 32) else DWBT(3, false, 32, 16) else return fail(-3, "conv_dwbt_k: shape not instantiated"); }
-#undef DWBT
-#undef DWBT_D
-        HIP_OK(hipGetLastError());
-    } else if (p.kind == 33) {
-        dim3 grid(p.npb, l.cin / 32, l.cout / 32), block(kBlock);
-        const int bf = a.act_bf16 ? 1 : 0;
-        char nm[64]; snprintf(nm, sizeof nm, "conv_dwbx_k<%d,%s,%d,%s>", l.kh, up ? "true" : "false", bf ? 1 : 3, AT_NAME(bf));
-        ProfScope ps(s, nm, l.name, fl, by);
-        const bool dr = (a.flags & F_DROP) != 0;          // dropout on the input: only the up-conv behind the bottleneck
-        if (dr && !up) return fail(-3, "conv_dwbx_k: dropout on the input is only built for the up-conv");
-        if (up && dr) { if (bf) conv_dwbx_k<2, true, 1, bf16_t, true><<<grid, block, 0, s>>>(a); else conv_dwbx_k<2, true, 3, float, true><<<grid, block, 0, s>>>(a); }
-        else if (up) { if (bf) conv_dwbx_k<2, true, 1, bf16_t><<<grid, block, 0, s>>>(a); else conv_dwbx_k<2, true, 3, float><<<grid, block, 0, s>>>(a); }
-        else { if (bf) conv_dwbx_k<3, false, 1, bf16_t><<<grid, block, 0, s>>>(a); else conv_dwbx_k<3, false, 3, float><<<grid, block, 0, s>>>(a); }
-        HIP_OK(hipGetLastError());
+    } else if (p.kind == 33 || p.kind == 34) {
+        rc = launch_dw_bf16pipe(a, p, l.kh, up, lc);
     } else {
-        dim3 grid(p.npb, cdiv(l.cin, p.cic), cdiv(l.cout, p.coc)), block(kBlock);
-        char nm[64];
-        if (p.kind == 16 && !up && l.cout == 8 && l.kh == 3 && g_dwpair8) snprintf(nm, sizeof nm, "conv_dwpair8_k<%d,%s>", p.cic, AT_NAME(a.act_bf16));
-        else if (p.kind == 16) snprintf(nm, sizeof nm, "conv_dw16_k<%d,%d,%s,%s>", l.kh, p.cic, up ? "true" : "false", AT_NAME(a.act_bf16));
-        else snprintf(nm, sizeof nm, "conv_dw32_k<%d,%d,%s,%d,%s>", l.kh, p.cic, up ? "true" : "false", p.th, AT_NAME(a.act_bf16));
-        ProfScope ps(s, nm, l.name, fl, by);
-        if (p.kind == 16 && !up && l.cout == 8 && l.kh == 3 && g_dwpair8) {
-            grid = dim3(p.npb, cdiv(l.cin, p.cic), 1);
-            if (p.cic == 16) AT_DISPATCH(a.act_bf16, conv_dwpair8_k<16, AT><<<grid, block, 0, s>>>(a));
-            else AT_DISPATCH(a.act_bf16, conv_dwpair8_k<8, AT><<<grid, block, 0, s>>>(a));
-        } else if (p.kind == 16) {
-            if (up) { if (p.cic == 16) AT_DISPATCH(a.act_bf16, conv_dw16_k<2, 16, true, AT><<<grid, block, 0, s>>>(a)); else AT_DISPATCH(a.act_bf16, conv_dw16_k<2, 8, true, AT><<<grid, block, 0, s>>>(a)); }
-            else { if (p.cic == 16) AT_DISPATCH(a.act_bf16, conv_dw16_k<3, 16, false, AT><<<grid, block, 0, s>>>(a)); else AT_DISPATCH(a.act_bf16, conv_dw16_k<3, 8, false, AT><<<grid, block, 0, s>>>(a)); }
-        } else {
-            if (up) { if (p.cic == 64) AT_DISPATCH(a.act_bf16, conv_dw32_k<2, 64, true, 2, AT><<<grid, block, 0, s>>>(a)); else AT_DISPATCH(a.act_bf16, conv_dw32_k<2, 32, true, 4, AT><<<grid, block, 0, s>>>(a)); }
-            else { if (p.cic == 64) AT_DISPATCH(a.act_bf16, conv_dw32_k<3, 64, false, 2, AT><<<grid, block, 0, s>>>(a)); else AT_DISPATCH(a.act_bf16, conv_dw32_k<3, 32, false, 4, AT><<<grid, block, 0, s>>>(a)); }
-        }
-        HIP_OK(hipGetLastError());
+        rc = launch_dw_f32pipe(a, p, l.kh, up, lc);
     }
     if (rc) return rc;
     queue_reduce(h, l, a.npb);
     return 0;
 }
 
-// finalize + apply BN backward for block li (its g buffer holds masked gradients, stat_part the partials)
-int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s, bool finalize_only = false) {
+// finalize (and, unless the consumers apply it on load, apply) BN backward for block li: its g buffer holds masked
+// gradients, stat_part the partials
+int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s, bool finalize_only, bool finalized_in_launch) {
     const Layer& l = h->plan.L[li];
-    BnBwdFinArgs f{};
-    f.part = h->stat_part; f.nblk = nblk; f.C = l.cout; f.count = (double)B * l.H * l.W;
-    f.bn = l.bn; f.dgamma = h->grads + l.gamma_off; f.dbeta = h->grads + l.beta_off;
-    { ProfScope ps(s, "bn_bwd_finalize_k", l.name, 0, (double)nblk * 2 * l.cout * 4);
-      bn_bwd_finalize_k<<<l.cout, kBlock, 0, s>>>(f); }
-    if (finalize_only) { HIP_OK(hipGetLastError()); return 0; }      // the consumer applies the transform itself
+    if (!finalized_in_launch) {
+        BnBwdFinArgs f{};
+        f.part = h->stat_part; f.nblk = nblk; f.C = l.cout; f.count = (double)B * l.H * l.W;
+        f.bn = l.bn; f.gamma = h->params + l.gamma_off; f.dgamma = h->grads + l.gamma_off; f.dbeta = h->grads + l.beta_off;
+        ProfScope ps(s, "bn_bwd_finalize_k", l.name, 0, (double)nblk * 2 * l.cout * 4);
+        bn_bwd_finalize_k<<<l.cout, kBlock, 0, s>>>(f);
+        HIP_OK(hipGetLastError());
+    }
+    if (finalize_only) return 0;      // the consumers apply the transform themselves
     const size_t n4 = (size_t)B * l.H * l.W * l.cout / 4;
     const int grid = (int)std::min<size_t>((n4 + kBlock - 1) / kBlock, 8192);
     const int bf = h->cfg.dtype;
@@ -897,12 +636,12 @@ int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s, bool finali
         const size_t n8 = n4 / 2;
         const int grid8 = (int)std::min<size_t>((n8 + kBlock - 1) / kBlock, 8192);
         ProfScope ps(s, "bn_bwd_apply8_bf16_k", l.name, 0, (double)n4 * 8 * 3);
-        bn_bwd_apply8_bf16_k<<<grid8, kBlock, 0, s>>>((bf16_t*)l.g, (const bf16_t*)l.z, l.bn, h->params + l.gamma_off, n8, l.cout);
+        bn_bwd_apply8_bf16_k<<<grid8, kBlock, 0, s>>>((bf16_t*)l.g, (const bf16_t*)l.z, l.bn, n8, l.cout);
         HIP_OK(hipGetLastError());
         return 0;
     }
     ProfScope ps(s, bf ? "bn_bwd_apply_k<unsigned short>" : "bn_bwd_apply_k<float>", l.name, 0, (double)n4 * (bf ? 8 : 16) * 3);
-    AT_DISPATCH(bf, bn_bwd_apply_k<AT><<<grid, kBlock, 0, s>>>((AT*)l.g, (const AT*)l.z, l.bn, h->params + l.gamma_off, n4, l.cout));
+    AT_DISPATCH(bf, bn_bwd_apply_k<AT><<<grid, kBlock, 0, s>>>((AT*)l.g, (const AT*)l.z, l.bn, n4, l.cout));
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -916,11 +655,11 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     hb.z = last.z; hb.bn = last.bn; hb.w = h->params + hd.w_off; hb.bias = h->params + hd.b_off;
     hb.labels = labels; hb.bc = h->dice_bc; hb.g = last.g; hb.part = h->stat_part; hb.wpart = hd.dwp;
     hb.HW = hd.H * hd.W; hb.nblk = head_nblk(hb.HW, B); hb.B = B; hb.macro = macro; hb.loss_scale = loss_scale; hb.act_bf16 = h->cfg.dtype;
-    hb.focal_w = h->focal_w; hb.focal_gamma = h->focal_gamma; hb.focal_cw = h->focal_cw; hb.focal_clip_mod = g_focal_clip_mod; hb.inv_count = 1.f / ((float)B * hb.HW);
+    hb.focal_w = h->focal_w; hb.focal_gamma = h->focal_gamma; hb.focal_cw = h->focal_cw; hb.focal_clip_mod = h->opt.focal_clip_mod; hb.inv_count = 1.f / ((float)B * hb.HW);
     // backward-data weights of every block for this step's parameters: transposed / effective fp32 kernels, then their
     // bf16 operand layouts.  Nothing needs them before the first backward-data launch, so they run on the side stream
     // under the head backward and the last block's BN backward.
-    const bool side_ok = g_dw_side_stream && h->side && !(t_prof && t_prof->on);
+    const bool side_ok = h->opt.dw_side_stream && h->side && !(t_prof && t_prof->on);
     hipStream_t ps_ = side_ok ? h->side : s;
     if (side_ok) { HIP_OK(hipEventRecord(h->fork_ev[0], s)); HIP_OK(hipStreamWaitEvent(h->side, h->fork_ev[0], 0)); }
     {
@@ -928,12 +667,12 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         prep_wt_k<<<std::min<unsigned>((h->wt_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, ps_>>>(h->wt_descs, h->n_wt, h->wt_total);
         HIP_OK(hipGetLastError());
     }
-    if (g_mfma_mode && h->n_wbx_b) {
+    if (h->opt.mfma_mode && h->n_wbx_b) {
         ProfScope ps(ps_, "prep_wbx_k", "all", 0, (double)h->wbx_b_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
         prep_wbx_k<<<std::min<unsigned>((h->wbx_b_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, ps_>>>(h->wbx_descs + h->n_wbx_f, h->n_wbx_b, h->wbx_b_total);
         HIP_OK(hipGetLastError());
     }
-    if (g_mfma_mode && h->n_wbt_b) {
+    if (h->opt.mfma_mode && h->n_wbt_b) {
         ProfScope ps(ps_, "prep_wbt_k", "all", 0, (double)h->wbt_b_total * 8 * (4 + 2 * (h->cfg.dtype ? 1 : 3)));
         prep_wbt_k<<<std::min<unsigned>((h->wbt_b_total + kBlock - 1) / kBlock, 2048u), kBlock, 0, ps_>>>(h->wbt_descs + h->n_wbt_f, h->n_wbt_b, h->wbt_b_total);
         HIP_OK(hipGetLastError());
@@ -949,21 +688,51 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
 
     for (int li = nl - 2; li >= 0; --li) {
         Layer& l = pl.L[li];
-        // g buffer of block li is complete (+ partials in stat_part) -> dz in place
-        // (first layer: its dz has ONE consumer, the backward-weights kernel, which then applies the transform on load)
-        const bool fuse0 = g_fuse_first_apply && li == 0 && first_dw_streams(l) && dw_plan(l, B, g_mfma_mode, h->cfg.dtype).kind == 0 &&
-                           !(src_of(h, li, x_in, x_is_u8).flags & (F_AFF | F_DROP | F_TWO | F_UP));
-        rc = bn_backward(h, li, pending_nblk, B, s, fuse0);
+        const Options& o = h->opt;
+        // backward-data launches of this block: dz x transposed / effective weights through the MFMA implicit-GEMM kernels
+        auto dx_args = [&](void* gout, int Cg, int ci_off, const Layer* prod, bool up) {
+            IgemmArgs g{};
+            g.x0 = l.g; g.C0 = l.cout; g.flags = 0; g.Cin = l.cout;
+            g.w = l.wt; g.w_ld = l.cin; g.m_off = ci_off; g.out = gout; g.Mout = Cg;
+            g.Hi = l.H; g.Wi = l.W; g.Ho = up ? l.H / 2 : l.H; g.Wo = up ? l.W / 2 : l.W;
+            g.part = prod ? h->stat_part : nullptr; g.zin = prod ? prod->z : nullptr; g.bnin = prod ? prod->bn : nullptr;
+            g.drop_out = (up && l.drop_in) ? 1 : 0; g.drop = make_drop(h); g.act_bf16 = h->cfg.dtype;
+            g.wbx = l.wbx_b; g.wbx_M = l.cin;
+            g.wbt = l.wbt_b ? l.wbt_b + (size_t)(ci_off / Cg) * (wbt_bytes(3, l.cout, h->cfg.dtype ? 1 : 3, l.bt_m2_b) / 2) : nullptr;
+            g.bt_m2 = l.bt_m2_b;
+            return g;
+        };
+        // g buffer of block li is complete (+ partials in stat_part).  Its BN-backward transform dz = ga g' + gb z + gd is
+        // applied by the consumers of dz while they stage it -- the backward-weights kernel and the backward-data launches --
+        // whenever all of them can (the bf16-pipe conv kernels and every MFMA backward-weights kernel); otherwise by the
+        // stand-alone pass, in place.  First layer: its dz has ONE consumer, the streaming backward-weights kernel.
+        const int dwkind = dw_plan(l, B, o.mfma_mode, h->cfg.dtype, o).kind;
+        bool fuse;
+        if (l.src == SRC_INPUT) {
+            fuse = o.fuse_first_apply && li == 0 && first_dw_streams(l) && dwkind == 0 &&
+                   !(src_of(h, li, x_in, x_is_u8).flags & (F_AFF | F_DROP | F_TWO | F_UP));
+        } else {
+            const int cg = bx_bwd_cg(l);
+            const bool up = l.src == SRC_UP;
+            const ConvRoute r0 = conv_route(dx_args(nullptr, cg, 0, nullptr, up), up ? A_DOWN2 : A_NORMAL, o);
+            // (two bf16-pipe instantiations stay out: the stride-2 gather beyond the coefficient rows its LDS holds, and the
+            //  thin kernel at 32 K channels, whose staging registers for g' AND z no longer fit)
+            fuse = o.fuse_bn_apply && dwkind != 0 && r0 != ROUTE_F32 && !(up && r0 == ROUTE_BX && l.cout > kBxGbDown2MaxC) &&
+                   !(r0 == ROUTE_BT && l.cout == 32) &&
+                   (l.src != SRC_CONCAT || conv_route(dx_args(nullptr, cg, cg, nullptr, false), A_NORMAL, o) != ROUTE_F32);
+        }
+        l.g_masked = fuse;
+        rc = bn_backward(h, li, pending_nblk, B, s, fuse, false);
         if (rc) return rc;
         const bool fork = side_ok;     // (the per-launch profiler wants serial launches)
         if (fork) {
             hipEvent_t e = h->fork_ev[1 + li % (h->fork_ev.size() - 1)];
             HIP_OK(hipEventRecord(e, s));                        // dz of block li is final here
             HIP_OK(hipStreamWaitEvent(h->side, e, 0));
-            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, h->side, fuse0);
+            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, h->side, fuse);
             forked = true;
         } else {
-            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s, fuse0);
+            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s, fuse);
         }
         if (rc) return rc;
         if (h->tail_event && li == first_mid_layer(pl)) {
@@ -977,25 +746,18 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         }
         if (l.src == SRC_INPUT) break;
         if (prep_pending) { HIP_OK(hipStreamWaitEvent(s, h->prep_ev, 0)); prep_pending = false; }   // first backward-data launch
-        // backward-data through the MFMA implicit-GEMM kernel: dz (plain) x transposed / effective weights
         int rows = 0;
         auto dx = [&](void* gout, int Cg, int ci_off, const Layer* prod, bool up) -> int {
-            IgemmArgs g{};
-            g.x0 = l.g; g.C0 = l.cout; g.flags = 0; g.Cin = l.cout;
-            g.w = l.wt; g.w_ld = l.cin; g.m_off = ci_off; g.out = gout; g.Mout = Cg;
-            g.Hi = l.H; g.Wi = l.W; g.Ho = up ? l.H / 2 : l.H; g.Wo = up ? l.W / 2 : l.W;
-            g.part = prod ? h->stat_part : nullptr; g.zin = prod ? prod->z : nullptr; g.bnin = prod ? prod->bn : nullptr;
-            g.drop_out = (up && l.drop_in) ? 1 : 0; g.drop = make_drop(h); g.act_bf16 = h->cfg.dtype;
-            g.wbx = l.wbx_b; g.wbx_M = l.cin;
-            g.wbt = l.wbt_b ? l.wbt_b + (size_t)(ci_off / Cg) * (wbt_bytes(3, l.cout, h->cfg.dtype ? 1 : 3, l.bt_m2_b) / 2) : nullptr;
-            g.bt_m2 = l.bt_m2_b;
+            IgemmArgs g = dx_args(gout, Cg, ci_off, prod, up);
+            if (fuse) { g.gb_z = l.z; g.gb_bn = l.bn; }
             const double px = (double)B * l.H * l.W, pxg = (double)B * g.Ho * g.Wo;
             const double fl = 2.0 * l.kh * l.kw * Cg * l.cout * px;          // algorithmic flops of the original conv's dX
             const int es = h->cfg.dtype ? 2 : 4;
-            const double by = px * l.cout * es + pxg * Cg * es * (prod ? 2 : 1);
-            if (up) return launch_igemm<3, A_DOWN2, EPI_MASK>(g, B, s, l.name, fl, by, &rows);
-            return prod ? launch_igemm<3, A_NORMAL, EPI_MASK>(g, B, s, l.name, fl, by, &rows)
-                        : launch_igemm<3, A_NORMAL, EPI_RAW>(g, B, s, l.name, fl, by, &rows);
+            const double by = px * l.cout * es * (fuse ? 2 : 1) + pxg * Cg * es * (prod ? 2 : 1);
+            const LaunchCtx lc{&o, B, s, l.name, fl, by};
+            if (up) return launch_igemm<3, A_DOWN2, EPI_MASK>(g, lc, &rows);
+            return prod ? launch_igemm<3, A_NORMAL, EPI_MASK>(g, lc, &rows)
+                        : launch_igemm<3, A_NORMAL, EPI_RAW>(g, lc, &rows);
         };
         switch (l.src) {
             case SRC_PREV: {
@@ -1066,7 +828,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
 extern "C" {
 
 const char* oct_last_error(void) { return g_err.c_str(); }
-const char* oct_version(void) { return "oct_unet_hip 0.1 (gfx950)"; }
+const char* oct_version(void) { return "oct_unet_hip 0.3 (gfx950) src:" OCT_SRC_HASH; }
 
 void oct_unet_cfg_default(oct_unet_cfg* c) {
     if (!c) return;
@@ -1086,7 +848,7 @@ int oct_unet_layer_count(const oct_unet_cfg* c) { return check_cfg(c) ? -1 : (in
 size_t oct_unet_workspace_bytes(const oct_unet_cfg* c) {
     if (check_cfg(c)) return 0;
     Plan pl = build_plan(*c);
-    return carve(*c, pl, nullptr, nullptr);
+    return carve(*c, pl, nullptr, nullptr, g_opt);
 }
 
 int oct_unet_layer_info(const oct_unet_cfg* c, int index, oct_layer_info* out) {
@@ -1110,14 +872,14 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
     if (!out || !params || !state || !ws) return fail(-1, "null pointer argument");
     if (c->training && !grads) return fail(-1, "training handle needs a grads buffer");
     oct_unet* h = new oct_unet();
-    h->cfg = *c; h->plan = build_plan(*c);
+    h->cfg = *c; h->plan = build_plan(*c); h->opt = g_opt;
     h->params = params; h->grads = grads; h->state = state;
-    const size_t need = carve(*c, h->plan, nullptr, nullptr);
+    const size_t need = carve(*c, h->plan, nullptr, nullptr, h->opt);
     if (ws_bytes < need) { delete h; return fail(-4, "workspace too small: need " + std::to_string(need) + " bytes"); }
     if (((uintptr_t)ws & 255) || ((uintptr_t)params & 15) || ((uintptr_t)state & 15) || (grads && ((uintptr_t)grads & 15))) {
         delete h; return fail(-1, "buffers must be aligned (workspace 256 B, params/grads/state 16 B)");
     }
-    carve(*c, h->plan, h, (char*)ws);
+    carve(*c, h->plan, h, (char*)ws, h->opt);
     if (c->training) {
         std::vector<WtDesc> d;
         unsigned off = 0;
@@ -1383,44 +1145,56 @@ int oct_boundary_maps(const unsigned char* labels, int B, int H, int W, int n_cl
 }
 
 namespace {
-struct Opt { const char* name; int* var; int lo; };
+struct Opt { const char* name; int Options::*var; int lo, hi; };     // values are clamped to [lo, hi]
 const Opt k_opts[] = {
-    {"igemm_persistent_min_tiles", &g_persist_min_tiles, 1}, {"dw32_blocks", &g_dw32_blocks, 64},
-    {"dw16_blocks", &g_dw16_blocks, 64}, {"igemm_persistent_blocks", &g_igemm_p_blocks, 8},
-    {"igemm_min_blocks", &g_igemm_min_blocks, 1}, {"dwpair8_enable", &g_dwpair8, 0},
-    {"pair8_geometry", &g_pair_geo, 111}, {"pair8_min_tiles", &g_pair_min_tiles, 1}, {"thin8_min_tiles", &g_thin_min_tiles, 1},
-    {"focal_clip_modulation", &g_focal_clip_mod, 0}, {"mfma_mode", &g_mfma_mode, 0}, {"bx_min_blocks", &g_bx_min_blocks, 1}, {"dwbx_blocks", &g_dwbx_blocks, 8}, {"bt_blocks_per_cu", &g_bt_blocks_per_cu, 0}, {"dwbt_f32_all", &g_dwbt_f32_all, 0}, {"bt_m2", &g_bt_m2, 0}, {"fuse_first_apply", &g_fuse_first_apply, 0}, {"bx_waves", &g_bx_waves, 4}, {"dw_side_stream", &g_dw_side_stream, 0},
+    {"igemm_persistent_min_tiles", &Options::persist_min_tiles, 1, 1 << 30}, {"dw32_blocks", &Options::dw32_blocks, 64, 1 << 20},
+    {"dw16_blocks", &Options::dw16_blocks, 64, 1 << 20}, {"igemm_persistent_blocks", &Options::igemm_p_blocks, 8, 1 << 20},
+    {"igemm_min_blocks", &Options::igemm_min_blocks, 1, 1 << 30}, {"dwpair8_enable", &Options::dwpair8, 0, 1},
+    {"pair8_geometry", &Options::pair_geo, 111, 221}, {"pair8_min_tiles", &Options::pair_min_tiles, 1, 1 << 30},
+    {"thin8_min_tiles", &Options::thin_min_tiles, 1, 1 << 30}, {"focal_clip_modulation", &Options::focal_clip_mod, 0, 1},
+    {"mfma_mode", &Options::mfma_mode, 0, 1}, {"bx_min_blocks", &Options::bx_min_blocks, 1, 1 << 30},
+    {"dwbx_blocks", &Options::dwbx_blocks, 8, 1 << 20}, {"bt_blocks_per_cu", &Options::bt_blocks_per_cu, 0, 8},
+    {"dwbt_f32_all", &Options::dwbt_f32_all, 0, 1}, {"bt_m2", &Options::bt_m2, 0, 1},
+    {"fuse_first_apply", &Options::fuse_first_apply, 0, 1}, {"fuse_bn_apply", &Options::fuse_bn_apply, 0, 1},
+    {"fuse_bn_finalize", &Options::fuse_bn_finalize, 0, 1}, {"bx_waves", &Options::bx_waves, 4, 8},
+    {"dw_side_stream", &Options::dw_side_stream, 0, 1},
 };
 }  // namespace
 
 int oct_get_option(const char* name, int* value) {
     if (!name || !value) return fail(-1, "null argument");
-    for (const Opt& o : k_opts) if (!strcmp(name, o.name)) { *value = *o.var; return 0; }
+    for (const Opt& o : k_opts) if (!strcmp(name, o.name)) { *value = g_opt.*o.var; return 0; }
     return fail(-1, std::string("unknown option: ") + name);
 }
 
 int oct_set_option(const char* name, int value) {
     if (!name) return fail(-1, "null option name");
-    if (!strcmp(name, "igemm_persistent_min_tiles")) { g_persist_min_tiles = value < 1 ? 1 : value; return 0; }
-    if (!strcmp(name, "dw32_blocks")) { g_dw32_blocks = value < 64 ? 64 : value; return 0; }
-    if (!strcmp(name, "dw16_blocks")) { g_dw16_blocks = value < 64 ? 64 : value; return 0; }
-    if (!strcmp(name, "igemm_persistent_blocks")) { g_igemm_p_blocks = value < 8 ? 8 : value; return 0; }
-    if (!strcmp(name, "igemm_min_blocks")) { g_igemm_min_blocks = value < 1 ? 1 : value; return 0; }
-    if (!strcmp(name, "dwpair8_enable")) { g_dwpair8 = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "pair8_geometry")) { if (value != 221 && value != 111) return fail(-1, "pair8_geometry must be 221 or 111"); g_pair_geo = value; return 0; }
-    if (!strcmp(name, "pair8_min_tiles")) { g_pair_min_tiles = value < 1 ? 1 : value; return 0; }
-    if (!strcmp(name, "thin8_min_tiles")) { g_thin_min_tiles = value < 1 ? 1 : value; return 0; }
-    if (!strcmp(name, "focal_clip_modulation")) { g_focal_clip_mod = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "mfma_mode")) { g_mfma_mode = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "bx_min_blocks")) { g_bx_min_blocks = value < 1 ? 1 : value; return 0; }
-    if (!strcmp(name, "dwbx_blocks")) { g_dwbx_blocks = value < 8 ? 8 : value; return 0; }
-    if (!strcmp(name, "bt_blocks_per_cu")) { g_bt_blocks_per_cu = value < 0 ? 0 : value; return 0; }
-    if (!strcmp(name, "dwbt_f32_all")) { g_dwbt_f32_all = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "bt_m2")) { g_bt_m2 = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "fuse_first_apply")) { g_fuse_first_apply = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "dw_side_stream")) { g_dw_side_stream = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "bx_waves")) { if (value != 4 && value != 8) return fail(-1, "bx_waves must be 4 or 8"); g_bx_waves = value; return 0; }
+    if (!strcmp(name, "pair8_geometry") && value != 221 && value != 111) return fail(-1, "pair8_geometry must be 221 or 111");
+    if (!strcmp(name, "bx_waves") && value != 4 && value != 8) return fail(-1, "bx_waves must be 4 or 8");
+    for (const Opt& o : k_opts)
+        if (!strcmp(name, o.name)) { g_opt.*o.var = value < o.lo ? o.lo : (value > o.hi ? o.hi : value); return 0; }
     return fail(-1, std::string("unknown option: ") + name);
+}
+
+int oct_unet_get_option(const oct_unet* h, const char* name, int* value) {
+    if (!h || !name || !value) return fail(-1, "null argument");
+    for (const Opt& o : k_opts) if (!strcmp(name, o.name)) { *value = h->opt.*o.var; return 0; }
+    return fail(-1, std::string("unknown option: ") + name);
+}
+
+int oct_unet_set_option(oct_unet* h, const char* name, int value) {
+    if (!h || !name) return fail(-1, "null argument");
+    if (!strcmp(name, "bt_m2")) return fail(-1, "bt_m2 shapes the prepared weights: set the default before oct_unet_create");
+    if (!strcmp(name, "pair8_geometry") && value != 221 && value != 111) return fail(-1, "pair8_geometry must be 221 or 111");
+    if (!strcmp(name, "bx_waves") && value != 4 && value != 8) return fail(-1, "bx_waves must be 4 or 8");
+    for (const Opt& o : k_opts)
+        if (!strcmp(name, o.name)) { h->opt.*o.var = value < o.lo ? o.lo : (value > o.hi ? o.hi : value); return 0; }
+    return fail(-1, std::string("unknown option: ") + name);
+}
+
+int oct_unet_debug_layer_fused(const oct_unet* h, int layer) {
+    if (!h || layer < 0 || layer >= (int)h->plan.L.size()) return -1;
+    return h->plan.L[layer].g_masked ? 1 : 0;
 }
 
 const void* oct_unet_debug_activation(oct_unet* h, int layer, int which) {

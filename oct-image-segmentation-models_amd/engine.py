@@ -237,7 +237,7 @@ class UNetEngine:
     def mfma_products(self) -> int:
         """0: the convolutions run on the f32 MFMA pipe.  n > 0: on the bf16 pipe, n bf16 products per product
         (6 = exact three-term split of both fp32 operands, csrc/kernels_bx.hpp; 1 = bf16 operands, cfg.dtype 1)."""
-        if not _hip.get_option("mfma_mode"):
+        if not self.handle_option("mfma_mode"):
             return 0
         return 1 if self.cfg.dtype == 1 else 6
 
@@ -342,13 +342,42 @@ class UNetEngine:
         self.params.copy_(torch.from_numpy(p)); self.state.copy_(torch.from_numpy(s))
 
     def debug_bn_record(self, layer: int) -> torch.Tensor:
-        """The (6, cout) f32 BN record the consumers of ``layer`` apply on load: rows a, b, mean, rstd, c1, c2."""
+        """The (9, cout) f32 BN record of ``layer``: rows a, b, mean, rstd (consumers apply relu(a*z + b) on load), c1, c2
+        (BN-backward means) and ga, gb, gd (the BN-backward transform dz = ga*g' + gb*z + gd)."""
         ptr = _hip.lib().oct_unet_debug_activation(self._h, layer, 2)
         if not ptr:
             raise OctError("no BN record for this layer")
         c = self.layers[layer]["cout"]
         off = ptr - self.workspace.data_ptr()
-        return self.workspace[off:off + 4 * 6 * c].view(torch.float32).view(6, c)
+        return self.workspace[off:off + 4 * 9 * c].view(torch.float32).view(9, c)
+
+    def debug_layer_fused(self, layer: int) -> bool:
+        """True if, in the last backward, the layer's BN-backward transform was applied on load by its consumers: its
+        gradient buffer (``debug_activation(layer, 1)``) then holds the masked gradient g', not dz."""
+        r = _hip.lib().oct_unet_debug_layer_fused(self._h, layer)
+        if r < 0:
+            raise OctError("no such layer")
+        return bool(r)
+
+    def debug_dz(self, layer: int) -> torch.Tensor:
+        """dz of ``layer`` after a backward, float64: the gradient buffer itself where the stand-alone BN-backward pass
+        ran, else the transform of the stored g' and z with the record's rows (what the consumers formed on load)."""
+        g = self.debug_activation(layer, 1).double()
+        if not self.debug_layer_fused(layer):
+            return g
+        rec = self.debug_bn_record(layer).double()
+        return rec[6] * g + (rec[7] * self.debug_activation(layer, 0).double() + rec[8])
+
+    def set_option(self, name: str, value: int) -> None:
+        """Edit this handle's copy of a tuning / arithmetic option (``_hip.set_option`` edits the defaults new handles copy)."""
+        _hip.check(_hip.lib().oct_unet_set_option(self._h, name.encode(), int(value)), f"oct_unet_set_option({name})")
+
+    def handle_option(self, name: str) -> int:
+        """The value of a tuning option as this handle snapshotted it at creation."""
+        import ctypes as C
+        v = C.c_int(0)
+        _hip.check(_hip.lib().oct_unet_get_option(self._h, name.encode(), C.byref(v)), f"oct_unet_get_option({name})")
+        return int(v.value)
 
     def debug_activation(self, layer: int, which: int = 0) -> torch.Tensor:
         """A layer's saved pre-BN output (which=0) or gradient buffer (which=1), max_batch-sized; a float32 view in

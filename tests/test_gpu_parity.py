@@ -57,7 +57,8 @@ DROP_STEP = 3
 
 
 @pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111", "dw16_padded",
-                        "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all", "bt_one_px", "first_apply_separate"])
+                        "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all", "bt_one_px", "bn_apply_separate",
+                        "bn_finalize_separate"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant: for the thin layers the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels (otherwise only chosen on large grids); for the wide layers the
@@ -70,7 +71,9 @@ def variant(request):
     _hip.set_option("mfma_mode", 0 if v == "f32_pipe" else 1)
     _hip.set_option("dwbt_f32_all", 1 if v == "dwbt_all" else 0)     # fp32 mode: every thin dW shape on the bf16 pipe
     _hip.set_option("bt_m2", 0 if v == "bt_one_px" else 1)           # thin kernel: 8-channel launches without the two-pixel form
-    _hip.set_option("fuse_first_apply", 0 if v == "first_apply_separate" else 1)   # block 0: bn_bwd_apply as its own pass
+    _hip.set_option("fuse_first_apply", 0 if v == "bn_apply_separate" else 1)   # bn_bwd_apply as its own pass: block 0 ...
+    _hip.set_option("fuse_bn_apply", 0 if v == "bn_apply_separate" else 1)      # ... and every other block
+    _hip.set_option("fuse_bn_finalize", 0 if v == "bn_finalize_separate" else 1)   # bn_*_finalize as their own launches
     _hip.set_option("igemm_persistent_min_tiles", 1 if v == "persistent" else 1 << 30)
     _hip.set_option("thin8_min_tiles", 1 if v == "thin8_valu" or v.startswith("pair8") else 1 << 30)
     _hip.set_option("pair8_min_tiles", 1 if v.startswith("pair8") else 1 << 30)
@@ -83,6 +86,8 @@ def variant(request):
     _hip.set_option("dwbt_f32_all", 0)
     _hip.set_option("bt_m2", 1)
     _hip.set_option("fuse_first_apply", 1)
+    _hip.set_option("fuse_bn_apply", 1)
+    _hip.set_option("fuse_bn_finalize", 1)
     _hip.set_option("dwpair8_enable", 1)
     _hip.set_option("igemm_persistent_min_tiles", 2048)
     _hip.set_option("thin8_min_tiles", 2048)
@@ -152,17 +157,21 @@ def test_training_step_matches_oracle(case, macro, variant):
     assert abs(loss4[3] - on.dice_coef_micro(y, ref)) < DICE_TOL
 
     loss, grads = on.backward(cfg, p64, cache, labels, macro=macro, loss_scale=0.5)
-    # layer-wise dz from the last block backwards
-    # (block 0 on the default route: its BN-backward transform is applied inside the backward-weights kernel, so its
-    # buffer keeps the masked gradient g' -- that dz is checked through the block's kernel / bias gradients below and
-    # directly in the "first_apply_separate" variant)
-    from oct_image_segmentation_models_amd import _hip
-    fused0 = _hip.get_option("fuse_first_apply") == 1 and ic == 1 and sn == 8
-    for li in range(len(plan) - 2, 0 if fused0 else -1, -1):
-        dz = eng.debug_activation(li, 1)[:B].cpu().numpy()
+    # layer-wise dz from the last block backwards.  On the default route the BN-backward transform is applied by the
+    # consumers of dz while they stage it and the buffer keeps the masked gradient g': debug_dz then forms
+    # ga g' + gb z + gd from the stored tensors and the record's rows, which pins g', the coefficients and (through the
+    # kernel / bias gradients below) what the stagers made of them; in the "bn_apply_separate" variant it is the buffer.
+    n_fused = 0
+    for li in range(len(plan) - 2, -1, -1):
+        n_fused += eng.debug_layer_fused(li)
+        dz = eng.debug_dz(li)[:B].cpu().numpy()
         ref_dz = cache[li]["dz"]
         scale = np.abs(ref_dz).max()
         assert np.abs(dz - ref_dz).max() / scale < 5e-4, f"layer {li} {plan[li].name} dz differs"
+    if variant == "bn_apply_separate" or variant == "f32_pipe":
+        assert n_fused == 0
+    elif sn % 8 == 0:
+        assert n_fused >= len(plan) - 3, n_fused          # (all but the thin kernel's 32-channel instantiations)
     g = eng.grads.cpu().numpy()
     for L_, gr in zip(eng.layers, grads):
         n = L_["kh"] * L_["kw"] * L_["cin"] * L_["cout"]; c = L_["cout"]
@@ -452,35 +461,42 @@ def test_focal_dice_loss_and_gradients_match_oracle(macro, cw):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_first_block_fused_bn_backward_equals_the_separate_pass(dtype):
-    """Block 0's dz has one consumer (its backward-weights kernel; the image has no gradient), so by default the
-    BN-backward transform dz = gamma*rstd*(g' - c1 - xhat*c2) is applied inside conv_dw_first_k instead of by a
-    bn_bwd_apply pass over the largest tensor of the net.  Same expression, same rounding of dz to the storage type:
-    every gradient must equal the separate-pass route BIT FOR BIT, in fp32 and in bf16 storage."""
+@pytest.mark.parametrize("geo", [(3, 40, 96, 3, 8, 3), (2, 32, 64, 4, 16, 2)])
+def test_bn_backward_on_load_equals_the_separate_pass(dtype, geo):
+    """By default no block's dz is ever stored: the BN-backward transform dz = ga g' + gb z + gd is applied by the
+    consumers of dz while they stage g' and z -- block 0 inside conv_dw_first_k (its only consumer; the image has no
+    gradient), every other block inside its backward-weights kernel and its backward-data launches -- instead of by a
+    bn_bwd_apply pass per block (3 tensor passes each).  Same two fmas, same rounding of dz to the storage type: every
+    gradient must equal the separate-pass route BIT FOR BIT, in fp32 and in bf16 storage."""
     from oct_image_segmentation_models_amd import _hip
     from oct_image_segmentation_models_amd.engine import UNetEngine
-    B, H, W, C = 3, 40, 96, 3                       # ragged against the 8 x 128 tile of the streaming kernel
+    B, H, W, C, sn, P = geo                         # first: ragged against the 8 x 128 tile of the streaming kernel
     images, labels = data(B, H, W, C, 1, seed=21)
     x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
-    got = {}
+    got, applied = {}, {}
     try:
         for fuse in (1, 0):
-            _hip.set_option("fuse_first_apply", fuse)
+            _hip.set_option("fuse_first_apply", fuse); _hip.set_option("fuse_bn_apply", fuse)
             eng = UNetEngine(device="cuda:0", input_channels=1, num_classes=C, image_height=H, image_width=W,
-                             start_neurons=8, pool_layers=3, max_batch=B, training=True, seed=9, init_seed=4,
+                             start_neurons=sn, pool_layers=P, max_batch=B, training=True, seed=9, init_seed=4,
                              dtype="bfloat16" if dtype == "bf16" else "float32")
             eng.set_dropout_step(2)
             eng.profile_begin()
             eng.forward(x, training=True, labels=lab, want_probs=False); eng.loss_dice(); eng.backward(lab, macro=True)
             names = [(e["kernel"], e["layer"]) for e in eng.profile_end()]
-            applied0 = any(k.startswith("bn_bwd_apply") and l == "enc0.conv0" for k, l in names)
-            assert applied0 == (fuse == 0), names            # the pass is really gone / really there
+            applied[fuse] = {l for k, l in names if k.startswith("bn_bwd_apply")}
+            nb = len(eng.layers) - 1
+            fused = {eng.layers[li]["name"] for li in range(nb) if eng.debug_layer_fused(li)}
+            assert applied[fuse] | fused == {L["name"] for L in eng.layers[:nb]} and not (applied[fuse] & fused), names
+            if fuse:       # the passes are really gone: at most the thin kernel's 32-channel backward-data layers keep theirs
+                assert len(applied[1]) <= P - 1 and (sn != 8 or "enc0.conv0" in fused), applied[1]
+                assert any(k.endswith(",gb>") for k, _ in names)
+            else:
+                assert not fused and not any(k.endswith(",gb>") for k, _ in names)
+                assert eng.debug_activation(0, 1)[:B].float().abs().sum().item() > 0
             got[fuse] = eng.grads.clone()
-            if fuse == 0:
-                dz0 = eng.debug_activation(0, 1)[:B].float().abs().sum().item()
-                assert dz0 > 0
     finally:
-        _hip.set_option("fuse_first_apply", 1)
+        _hip.set_option("fuse_first_apply", 1); _hip.set_option("fuse_bn_apply", 1)
     assert torch.isfinite(got[1]).all() and got[1].abs().max() > 0
     assert torch.equal(got[0], got[1])
 
@@ -508,16 +524,13 @@ def test_focal_clip_modulation_switch(clip_mod):
     ref, cache = on.forward(cfg, p64, s64, on.preprocess_u8(images, np.float64), training=True, dropout_mask=mask)
     py = np.take_along_axis(ref, labels.astype(np.int64), axis=-1)
     assert (py < 1e-7).mean() > 0.2                                             # the clip really is active
-    _hip.set_option("focal_clip_modulation", clip_mod)
-    try:
-        assert _hip.get_option("focal_clip_modulation") == clip_mod
-        eng.set_focal_dice(fw, gamma, cw)
-        eng.forward(x, training=True, labels=lab, want_probs=False)
-        v = eng.loss_focal_dice().cpu().numpy()
-        eng.backward(lab, macro=True, loss_scale=1.0)
-        g = eng.grads.cpu().numpy().astype(np.float64)
-    finally:
-        _hip.set_option("focal_clip_modulation", 0)
+    eng.set_option("focal_clip_modulation", clip_mod)        # per handle: the process-wide default stays 0
+    assert eng.handle_option("focal_clip_modulation") == clip_mod and _hip.get_option("focal_clip_modulation") == 0
+    eng.set_focal_dice(fw, gamma, cw)
+    eng.forward(x, training=True, labels=lab, want_probs=False)
+    v = eng.loss_focal_dice().cpu().numpy()
+    eng.backward(lab, macro=True, loss_scale=1.0)
+    g = eng.grads.cpu().numpy().astype(np.float64)
     focal = on.focal_loss_mean(labels, ref, gamma, cw, clip_modulation=bool(clip_mod))
     assert abs(v[4] - focal) < 2e-5 * max(1.0, focal), (v[4], focal)
     both = [on.backward(cfg, p64, cache, labels, macro=True, loss_scale=1.0, focal=(fw, gamma, cw),
@@ -671,7 +684,7 @@ def upconv_dx_effective(dz, kernel, round_w):
 @pytest.mark.parametrize("case", BF16_CASES)
 def test_bf16_storage_layer_local_rounding_is_exact(case, variant):
     from oct_image_segmentation_models_amd import _hip
-    _hip.set_option("fuse_first_apply", 0)        # this test reads EVERY block's dz buffer, block 0 included (the fused
+    _hip.set_option("fuse_first_apply", 0); _hip.set_option("fuse_bn_apply", 0)   # this test reads EVERY block's STORED dz (the fused
     B, H, W, C, sn, P, L, ic = case               # route is pinned bit for bit against this one by the test below)
     cfg, eng, p64, s64 = make_bf16(B, H, W, C, sn, P, L, ic)
     assert eng.workspace.numel() < 0.8 * make(B, H, W, C, sn, P, L, ic)[1].workspace.numel()   # partials stay fp32

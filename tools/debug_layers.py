@@ -21,7 +21,7 @@ def report(case, macro=True):
     plan = on.build_plan(cfg)
     print("case", case, "loss", loss4, "ref", loss)
     for li in range(len(plan) - 2, -1, -1):
-        dz = eng.debug_activation(li, 1)[:B].cpu().numpy(); r = cache[li]["dz"]
+        dz = eng.debug_dz(li)[:B].cpu().numpy(); r = cache[li]["dz"]
         e = np.abs(dz - r); sc = np.abs(r).max()
         idx = np.unravel_index(e.argmax(), e.shape)
         y = cache[li]["y"]
