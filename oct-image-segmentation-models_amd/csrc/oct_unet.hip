@@ -573,7 +573,7 @@ inline bool first_dw_streams(const Layer& l) {
 
 // backward-weights of block li.  fused_apply: `dz` is the masked gradient g' and the kernel applies the BN-backward
 // transform of the block on load (every kernel but the generic VALU one of odd first layers can)
-int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const void* dz, int B, hipStream_t s, bool fused_apply = false) {
+int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const void* dz, int B, hipStream_t s, bool fused_apply) {
     const Layer& l = h->plan.L[li];
     const Options& o = h->opt;
     const SrcDesc sd = src_of(h, li, x_in, x_is_u8);
