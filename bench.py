@@ -14,7 +14,13 @@ Prints ONE JSON line on rank 0 (contract in the task brief) with
     the launch stream by the library's own per-launch profiler, plus ``step_frac`` (whole step vs the SURVEY A.3
     roofline of THIS run's shape/dtype) and ``traffic_ratio`` (PMC bytes / algorithmic bytes per step, from the
     committed rocprofv3 --pmc passes named in ``traffic_source``);
-  * ``cpu_baseline``: the torch-CPU port of the reference path from oracle/, timed on this box's host cores.
+  * ``cpu_baseline``: the torch-CPU port of the reference path from oracle/, timed on this box's host cores;
+  * ``allreduce``: what RCCL itself reports (backend, world size, every rank's device) and the per-step cost of the two
+    gradient all-reduces.  At N = 1 the timed steps run WITHOUT a collective (that is the single-GPU metric); a short
+    extra leg then creates a ONE-rank RCCL communicator and drives the same exchange step through it
+    (``--no-collective-leg`` skips it, ``--force-collective`` puts it inside the timed region instead);
+  * ``fit``: B-scans/s of ``Model.fit`` fed by ``DataGenerator`` from a uint8 array set (host gather -> pinned double
+    buffer -> H2D -> step), i.e. the real training loop beside the resident-input ``value``.
 """
 import argparse
 import glob
@@ -130,6 +136,49 @@ def cpu_baseline(H, W, C, P, budget_s=20.0):
             "host_cpus": os.cpu_count(), "inference_ms_per_scan": round(inf_ms, 2)}
 
 
+def fit_throughput(eng, H, W, C, P, B, n_scans, resident_scans_per_s):
+    """The REAL training loop (reference training/training.py:358-407, common/data_generator.py:285-368): ``Model.fit``
+    over a uint8 array set through ``DataGenerator`` (aug "none", shuffled, batch B): per step a host gather of B scans
+    and labels, a copy into pinned double buffers, H2D, then the same step the headline number times."""
+    import numpy as np
+    import torch
+    from oct_image_segmentation_models_amd import optimizers
+    from oct_image_segmentation_models_amd.common import custom_losses, custom_metrics
+    from oct_image_segmentation_models_amd.common.data_generator import DataGenerator
+    from oct_image_segmentation_models_amd.common.synthetic import make_scans
+    from oct_image_segmentation_models_amd.models import get_model_class
+    base_i, base_l = make_scans(64, H, W, C, seed=77)
+    reps = (n_scans + 63) // 64
+    images = np.tile(base_i, (reps, 1, 1, 1))[:n_scans]; labels = np.tile(base_l, (reps, 1, 1, 1))[:n_scans]
+    mc = get_model_class("unet")(input_channels=1, num_classes=C, image_height=H, image_width=W, pool_layers=P)
+    model = mc.build_model()
+    model._device = str(eng.device)
+    model.compile(optimizer=optimizers.Adam(learning_rate=1e-3), loss=custom_losses.custom_loss_objects["dice_loss_macro"],
+                  metrics=[custom_metrics.training_monitor_metric_objects["dice_coef_macro"]])
+    gen = DataGenerator(images, labels, B, [], "none", (), False, mc.get_preprocess_input_fn(), seed=5)
+    warm = DataGenerator(images[:4 * B], labels[:4 * B], B, [], "none", (), False, mc.get_preprocess_input_fn(), seed=5)
+    model.fit(x=warm, epochs=1, verbose=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.fit(x=gen, epochs=1, verbose=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = len(gen) * B
+    # the host side alone: the generator + pinned staging without any GPU work
+    t1 = time.perf_counter()
+    for _ in range(len(gen)):
+        X, l = gen.next_batch_u8()
+        model._staged(("x", 0), X); model._staged(("l", 0), l)
+    host = time.perf_counter() - t1
+    v = n / dt
+    return {"value": round(v, 1), "unit": "B-scans/s", "scans": n, "batch": B, "epochs_timed": 1,
+            "vs_resident_inputs": round(v / resident_scans_per_s, 4),
+            "host_stage_scans_per_s": round(n / host, 1),
+            "what": "Model.fit(DataGenerator(uint8 images, labels, aug 'none', shuffle)) -- host gather, pinned double "
+                    "buffer, H2D, fwd + Dice + bwd + Adam per batch; `host_stage_scans_per_s` is the generator + pinned "
+                    "staging alone (one Python thread)"}
+
+
 def spawn_ranks(n):
     """``bench.py --gpus N`` started as a plain script: run the N ranks as a child (no GPU call has happened yet)."""
     with socket.socket() as s:
@@ -171,6 +220,11 @@ def main():
     ap.add_argument("--no-inference", action="store_true", help="train steps only (PMC passes)")
     ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after the whole backward (no side stream)")
     ap.add_argument("--dump-profile", default=None, help="write the per-(kernel, layer) launch table to this JSON file")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: create a one-rank RCCL communicator and run the gradient all-reduces inside the timed steps")
+    ap.add_argument("--no-collective-leg", action="store_true", help="N = 1: skip the extra one-rank RCCL leg")
+    ap.add_argument("--no-fit", action="store_true", help="skip the Model.fit / DataGenerator throughput leg")
+    ap.add_argument("--fit-scans", type=int, default=2048, help="uint8 scans in the Model.fit leg's array set")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # (the rehearsal flag travels to the ranks in the environment)
@@ -185,7 +239,7 @@ def main():
     # OCT_BENCH_REHEARSAL=1: multi-process rehearsal on a ONE-GPU box (all ranks share cuda:0, gloo collective);
     # never used by the driver -- real runs are one rank per GPU over RCCL
     rehearsal = os.environ.get("OCT_BENCH_REHEARSAL") == "1"
-    rank, local_rank, world = parallel.init("gloo" if rehearsal else "nccl")
+    rank, local_rank, world = parallel.init("gloo" if rehearsal else "nccl", force=args.force_collective)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", 0 if rehearsal else local_rank)
@@ -203,8 +257,9 @@ def main():
     reps = (B + nd - 1) // nd
     x = torch.from_numpy(np.tile(images, (reps, 1, 1, 1))[:B]).to(dev)
     lab = torch.from_numpy(np.tile(labels[..., 0], (reps, 1, 1))[:B].copy()).to(dev)
-    overlap = world > 1 and not args.no_overlap
+    overlap = parallel.collective_active() and not args.no_overlap
     reducer = parallel.GradReducer(eng, overlap=overlap)
+    rccl = parallel.describe() if parallel.collective_active() else None
 
     def train_step():
         eng.forward(x, training=True, labels=lab, want_probs=False)
@@ -248,12 +303,58 @@ def main():
         "config": {"workload": f"{cfg_label}: train step (fwd+Dice-macro+bwd+allreduce+Adam), per-GPU batch {B}, "
                                f"{H}x{W}x1, {C}-class, pool_layers={P}, start_neurons=8, random-init weights",
                    "global_batch": B * world, "parallelism": f"dp{world}",
-                   "allreduce": ("none" if world == 1 else
+                   "allreduce": ("none" if not parallel.collective_active() else
                                  ("2 segments, decoder half on a side stream under the encoder backward" if overlap
                                   else "1 flat all-reduce after backward"))},
         "step_ms_median_events": round(step_ms[len(step_ms) // 2], 4),
         "step_ms_min_events": round(step_ms[0], 4), "final_loss": round(final_loss, 5),
     }
+
+    # ---- the exchange step through RCCL: what the library reports, and what the two all-reduces cost per step ----
+    def time_collectives(red, nsteps):
+        """median us per step of [all-reduce of the tail segment on the side stream] and [of the encoder segment]"""
+        evs = []
+        for _ in range(nsteps):
+            eng.forward(x, training=True, labels=lab, want_probs=False); eng.loss_dice()
+            evs.append(red.backward_and_reduce(lab, macro=True, loss_scale=1.0 / world, timed=True))
+            eng.adam_step(lr=1e-3)
+        torch.cuda.synchronize()
+        cols = list(zip(*[[a.elapsed_time(b) * 1e3 for a, b in e] for e in evs if e]))
+        return [round(sorted(c)[len(c) // 2], 2) for c in cols]
+
+    if rccl is not None:
+        out["allreduce"] = dict(rccl, in_timed_region=True, overlap=bool(overlap), grad_floats=int(eng.grads.numel()),
+                                tail_offset=int(eng.grad_tail_offset()))
+        out["allreduce"]["us_per_step"] = time_collectives(reducer, 10)
+    elif world == 1 and not args.no_collective_leg and not rehearsal:
+        try:
+            import socket as _s
+            with _s.socket() as sk:
+                sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            parallel.init("nccl", force=True)
+            red1 = parallel.GradReducer(eng, overlap=True)
+            for _ in range(3):
+                time_collectives(red1, 1)
+            torch.cuda.synchronize(); tc = time.perf_counter()
+            ncol = 20
+            for _ in range(ncol):
+                eng.forward(x, training=True, labels=lab, want_probs=False); eng.loss_dice()
+                red1.backward_and_reduce(lab, macro=True, loss_scale=1.0); eng.adam_step(lr=1e-3)
+            torch.cuda.synchronize()
+            ms_with = (time.perf_counter() - tc) / ncol * 1e3
+            out["allreduce"] = dict(parallel.describe(), in_timed_region=False, overlap=True,
+                                    grad_floats=int(eng.grads.numel()), tail_offset=int(eng.grad_tail_offset()),
+                                    us_per_step=time_collectives(red1, 10), ms_per_step_with_collectives=round(ms_with, 4),
+                                    note="one-rank RCCL communicator on this GPU: tail event -> all-reduce(grads[off:]) on the "
+                                         "side stream -> all-reduce(grads[:off]) -> join, after the timed (collective-free) steps")
+            red1.close(); parallel.shutdown()
+        except Exception as e:      # noqa: BLE001  -- the leg must never cost the headline number
+            out["allreduce"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                parallel.shutdown()
+            except Exception:      # noqa: BLE001
+                pass
 
     # ---- inference: hipGraph-replayed forward (+argmax), batch 128, inputs resident ----
     if not args.no_inference:
@@ -331,6 +432,11 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         roof.update({"traffic": traffic, "traffic_source": src, "kernel": fam, "instantiations": len(inst),
+                     "measured": "HIP events recorded on the launch stream around every launch of 3 untimed steps; while "
+                                 "the profiler is on every launch runs ALONE (the handle's side stream is off), so "
+                                 "`achieved` is the kernel by itself -- inside a step the backward-weights kernels run "
+                                 "beside the backward-data chain and both take longer (the rocprofv3 summary under "
+                                 "profiles/ shows those in-step durations)",
                      "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                      "launches_per_step": dom["launches"] // nprof,
                      "share_of_step_kernel_time": round(dom["ms"] / total_ms, 4),
@@ -345,19 +451,39 @@ def main():
         out["kernel_time_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in top}
         out["roofline_top_kernels"] = {k: dict(roof_of(v), ms_per_step=round(v["ms"] / nprof, 4)) for k, v in top}
     # whole-step roofline context from THIS run's shape and dtype (SURVEY A.3 formulas)
+    # ... priced twice, each with ONE set of peaks: (a) SURVEY 8(d)'s model (the arithmetic the reference's dtype implies:
+    # f32 MFMA 157.3 TF or bf16 2500 TF; HBM 6.29 TB/s measured by a copy); (b) the arithmetic this engine actually runs
+    # (f32 mode: 6 bf16 products per product -> 2500 / 6 = 416.7 TF) against the HBM SPEC rate of 8 TB/s -- the peaks
+    # `roofline` / `roofline_top_kernels` use for single kernels
+    prod_used = eng.mfma_products()
+    used_peak = PEAK_F32_TFLOPS if prod_used == 0 else PEAK_BF16_TFLOPS / prod_used
+    cm_used = cost_model(H, W, C, 8, P, 2, es, used_peak, PEAK_HBM_GBS)
     out["step_vs_roofline"] = {"algorithmic_gflop_per_scan": round(cm["train_gflop"], 3),
                                "algorithmic_mb_per_scan": round(cm["train_mb"], 1),
-                               "roofline_us_per_scan": round(cm["train_us"], 2),
                                "achieved_us_per_scan": round(achieved_us, 2),
+                               "survey_model": {"peaks": f"{'f32 MFMA 157.3' if es == 4 else 'bf16 MFMA 2500'} TFLOP/s, HBM 6.29 TB/s (measured copy rate)",
+                                                "roofline_us_per_scan": round(cm["train_us"], 2),
+                                                "frac": round(cm["train_us"] / achieved_us, 4),
+                                                "inference_roofline_us_per_scan": round(cm["fwd_us"], 2)},
+                               "arithmetic_used": {"peaks": f"MFMA {used_peak:.1f} TFLOP/s ({mm.split(':')[0]}), HBM 8.0 TB/s (spec)",
+                                                   "roofline_us_per_scan": round(cm_used["train_us"], 2),
+                                                   "frac": round(cm_used["train_us"] / achieved_us, 4),
+                                                   "inference_roofline_us_per_scan": round(cm_used["fwd_us"], 2)},
+                               # (kept for readers of earlier rounds' records: the SURVEY-model figures)
+                               "roofline_us_per_scan": round(cm["train_us"], 2),
                                "frac": round(cm["train_us"] / achieved_us, 4),
-                               "inference_roofline_us_per_scan": round(cm["fwd_us"], 2),
-                               "peaks": f"{'f32 MFMA 157.3' if es == 4 else 'bf16 MFMA 2500'} TFLOP/s, HBM 6.29 TB/s measured"}
+                               "inference_roofline_us_per_scan": round(cm["fwd_us"], 2)}
     if rank == 0 and world == 1 and not args.no_inference and os.environ.get("OCT_BENCH_NO_E2E") != "1":
         try:
             from oct_image_segmentation_models_amd.evaluation import pipeline
             out.update(pipeline.bench_fields(eng, images, C))
         except ImportError:
             pass
+    if rank == 0 and world == 1 and not args.no_fit and not args.no_inference and args.act_dtype == "f32":
+        try:
+            out["fit"] = fit_throughput(eng, H, W, C, P, B, args.fit_scans, scans_per_s)
+        except Exception as e:      # noqa: BLE001
+            out["fit"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(H, W, C, P)
     if rank == 0:

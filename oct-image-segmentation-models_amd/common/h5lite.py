@@ -35,6 +35,7 @@ _types = {}
 H5F_ACC_RDONLY, H5F_ACC_RDWR, H5F_ACC_TRUNC = 0, 1, 2
 H5P_DEFAULT = 0
 H5S_ALL = 0
+H5S_SELECT_SET = 0          # H5S_seloper_t
 H5S_SCALAR = 0
 H5I_GROUP, H5I_DATASET = 2, 5
 H5T_INTEGER, H5T_FLOAT, H5T_STRING = 0, 1, 3
@@ -87,6 +88,7 @@ def lib() -> C.CDLL:
             "H5Screate_simple": (hid_t, [C.c_int, C.POINTER(hsize_t), C.POINTER(hsize_t)]),
             "H5Screate": (hid_t, [C.c_int]), "H5Sclose": (C.c_int, [hid_t]),
             "H5Sget_simple_extent_ndims": (C.c_int, [hid_t]),
+            "H5Sselect_hyperslab": (C.c_int, [hid_t, C.c_int, C.POINTER(hsize_t), C.POINTER(hsize_t), C.POINTER(hsize_t), C.POINTER(hsize_t)]),
             "H5Sget_simple_extent_dims": (C.c_int, [hid_t, C.POINTER(hsize_t), C.POINTER(hsize_t)]),
             "H5Tcopy": (hid_t, [hid_t]), "H5Tset_size": (C.c_int, [hid_t, C.c_size_t]), "H5Tclose": (C.c_int, [hid_t]),
             "H5Tset_strpad": (C.c_int, [hid_t, C.c_int]), "H5Tset_cset": (C.c_int, [hid_t, C.c_int]),
@@ -164,15 +166,35 @@ def _as_array(value) -> np.ndarray:
     return np.require(a, requirements="C")        # (np.ascontiguousarray would turn a scalar into a 1-vector)
 
 
-def _read(obj: int, tid: int, sid: int, reader, is_attr: bool):
-    """Read a dataset / attribute whose file type is ``tid`` and dataspace ``sid`` into numpy."""
+def _shape_of(sid: int) -> Tuple[int, ...]:
     l = lib()
     nd = l.H5Sget_simple_extent_ndims(sid)
-    shape: Tuple[int, ...] = ()
-    if nd > 0:
-        dims = (hsize_t * nd)()
-        l.H5Sget_simple_extent_dims(sid, dims, None)
-        shape = tuple(int(d) for d in dims)
+    if nd <= 0:
+        return ()
+    dims = (hsize_t * nd)()
+    l.H5Sget_simple_extent_dims(sid, dims, None)
+    return tuple(int(d) for d in dims)
+
+
+def _dtype_of(tid: int) -> np.dtype:
+    """numpy dtype of a file type (metadata only; variable-length strings report object like h5py)."""
+    l = lib()
+    cls, size = l.H5Tget_class(tid), int(l.H5Tget_size(tid))
+    if cls == H5T_STRING:
+        return np.dtype("O") if l.H5Tis_variable_str(tid) > 0 else np.dtype(f"S{size}")
+    if cls == H5T_INTEGER:
+        return np.dtype(f"{'u' if l.H5Tget_sign(tid) == H5T_SGN_NONE else 'i'}{size}")
+    if cls == H5T_FLOAT:
+        return np.dtype(f"f{size}")
+    raise H5Error(f"unsupported HDF5 type class {cls}")
+
+
+def _read(obj: int, tid: int, sid: int, reader, is_attr: bool, shape: Optional[Tuple[int, ...]] = None):
+    """Read a dataset / attribute whose file type is ``tid`` and dataspace ``sid`` into numpy (``shape``: the shape of
+    the selection being read when it is not the whole dataspace)."""
+    l = lib()
+    if shape is None:
+        shape = _shape_of(sid)
     cls, size = l.H5Tget_class(tid), int(l.H5Tget_size(tid))
     n = int(np.prod(shape)) if shape else 1
     if cls == H5T_STRING and l.H5Tis_variable_str(tid) > 0:
@@ -289,6 +311,36 @@ class Dataset(_Node):
         l = lib()
         tid, sid = self._meta()
         try:
+            shape = _shape_of(sid)
+            # a contiguous range (or one index) of the LEADING axis is read as a hyperslab: only those rows leave the file
+            # -- what the batch generators do on multi-GB train_images; anything fancier reads the dataset and indexes it
+            lead = key[0] if isinstance(key, tuple) and len(key) >= 1 else key
+            rest = key[1:] if isinstance(key, tuple) else ()
+            plain_rest = all(isinstance(k, slice) and k == slice(None) for k in rest) or rest == (Ellipsis,)
+            is_var = l.H5Tget_class(tid) == H5T_STRING and l.H5Tis_variable_str(tid) > 0
+            if shape and plain_rest and not is_var and isinstance(lead, (int, np.integer, slice)) and not isinstance(lead, bool):
+                if isinstance(lead, slice):
+                    lo, hi, st = lead.indices(shape[0]); single = False
+                else:
+                    i = int(lead) + (shape[0] if int(lead) < 0 else 0)
+                    if not 0 <= i < shape[0]:
+                        raise IndexError(f"index {int(lead)} out of range for axis 0 with size {shape[0]}")
+                    lo, hi, st, single = i, i + 1, 1, True
+                if st == 1:
+                    cnt = max(0, hi - lo)
+                    sub = (cnt,) + shape[1:]
+                    if cnt == 0 or 0 in sub:
+                        out = np.empty(sub, dtype=_dtype_of(tid))
+                    else:
+                        nd = len(shape)
+                        start, count = (hsize_t * nd)(lo, *([0] * (nd - 1))), (hsize_t * nd)(*sub)
+                        _chk(l.H5Sselect_hyperslab(sid, H5S_SELECT_SET, start, None, count, None), "H5Sselect_hyperslab")
+                        msid = _chk(l.H5Screate_simple(nd, count, None), "H5Screate_simple")
+                        try:
+                            out = _read(self._id, tid, sid, lambda o, mt, buf: l.H5Dread(o, mt, msid, sid, H5P_DEFAULT, buf), False, shape=sub)
+                        finally:
+                            l.H5Sclose(msid)
+                    return out[0] if single else out
             full = _read(self._id, tid, sid, lambda o, mt, buf: l.H5Dread(o, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf), False)
         finally:
             l.H5Tclose(tid); l.H5Sclose(sid)
@@ -298,11 +350,29 @@ class Dataset(_Node):
 
     @property
     def shape(self):
-        return np.shape(self[()])
+        """From the dataspace: no data is read."""
+        l = lib()
+        sid = l.H5Dget_space(self._id)
+        try:
+            return _shape_of(sid)
+        finally:
+            l.H5Sclose(sid)
 
     @property
     def dtype(self):
-        return np.asarray(self[()]).dtype
+        """From the file type: no data is read."""
+        l = lib()
+        tid = l.H5Dget_type(self._id)
+        try:
+            return _dtype_of(tid)
+        finally:
+            l.H5Tclose(tid)
+
+    def __len__(self):
+        sh = self.shape
+        if not sh:
+            raise TypeError("scalar dataset has no len()")
+        return sh[0]
 
 
 class Group(_Node):

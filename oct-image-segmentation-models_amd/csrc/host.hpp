@@ -30,6 +30,7 @@ struct Options {
     int bx_waves = 8;               // waves per block of conv_bx_k where the tile has >= 8 rows
     int fuse_first_apply = 1;       // the first conv's BN-backward transform is applied inside its backward-weights kernel
     int fuse_bn_apply = 1;          // every other block: the transform is applied by the dX / dW kernels while they stage g'
+    int timing_skip = 0;            // TIMING EXPERIMENTS ONLY (results become wrong): bit 0 / 1 = skip the forward / backward BN finalize launches after step 2
     int fuse_bn_finalize = 1;       // BN statistic partials are finalized by the last block of the producing launch
     int bt_m2 = 1;                  // conv_bt_k: 8-output-channel launches in the two-pixel form
     int dwbt_f32_all = 0;           // 1: fp32 mode also takes conv_dwbt_k for every thin shape

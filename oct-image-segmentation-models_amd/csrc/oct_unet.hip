@@ -389,7 +389,7 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
         return fail(-3, "conv_forward: channel count not a multiple of 4");
     }
     if (rc) return rc;
-    if (l.has_bn && training) {
+    if (l.has_bn && training && !(h->opt.timing_skip & 1 && h->drop_step > 2)) {
         ProfScope ps(s, "bn_fwd_finalize_k", l.name, 0, (double)stat_rows * 2 * l.cout * 4);
         BnFinArgs f{};
         f.part = h->stat_part; f.nblk = stat_rows; f.C = l.cout; f.count = (double)B * l.H * l.W;
@@ -620,7 +620,7 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
 // gradients, stat_part the partials
 int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s, bool finalize_only, bool finalized_in_launch) {
     const Layer& l = h->plan.L[li];
-    if (!finalized_in_launch) {
+    if (!finalized_in_launch && !(h->opt.timing_skip & 2 && h->drop_step > 2)) {
         BnBwdFinArgs f{};
         f.part = h->stat_part; f.nblk = nblk; f.C = l.cout; f.count = (double)B * l.H * l.W;
         f.bn = l.bn; f.gamma = h->params + l.gamma_off; f.dgamma = h->grads + l.gamma_off; f.dbeta = h->grads + l.beta_off;
@@ -1033,7 +1033,15 @@ int oct_unet_backward(oct_unet* h, const unsigned char* labels, int macro, float
     if (!h->last_training || !h->have_dice || !h->dice_final)
         return fail(-1, "backward needs a training forward with io.labels followed by oct_unet_loss_dice");
     t_prof = &h->prof;
-    return backward_impl(h, h->last_x, h->last_u8, labels, macro, loss_scale, (hipStream_t)stream);
+    const int rc = backward_impl(h, h->last_x, h->last_u8, labels, macro, loss_scale, (hipStream_t)stream);
+    if (rc && h->side && h->join_ev) {
+        // an error part-way: work may have been forked to the internal side stream -- join it to the caller's stream before
+        // returning, so that the caller's stream order covers everything this call launched
+        const std::string msg = oct_last_error();
+        if (hipEventRecord(h->join_ev, h->side) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)stream, h->join_ev, 0);
+        fail(rc, msg);
+    }
+    return rc;
 }
 
 int oct_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
@@ -1157,7 +1165,7 @@ const Opt k_opts[] = {
     {"dwbt_f32_all", &Options::dwbt_f32_all, 0, 1}, {"bt_m2", &Options::bt_m2, 0, 1},
     {"fuse_first_apply", &Options::fuse_first_apply, 0, 1}, {"fuse_bn_apply", &Options::fuse_bn_apply, 0, 1},
     {"fuse_bn_finalize", &Options::fuse_bn_finalize, 0, 1}, {"bx_waves", &Options::bx_waves, 4, 8},
-    {"dw_side_stream", &Options::dw_side_stream, 0, 1},
+    {"dw_side_stream", &Options::dw_side_stream, 0, 1}, {"timing_skip", &Options::timing_skip, 0, 255},
 };
 }  // namespace
 

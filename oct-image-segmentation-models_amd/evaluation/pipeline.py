@@ -53,6 +53,10 @@ class BatchedPredictor:
 
         def upload(i):
             lo, hi, s = i * B, min(n, (i + 1) * B), i & 1
+            if i >= 2:
+                # the async H2D of batch i-2 READS this pinned buffer: the host must not overwrite it before that copy has
+                # run (the device-side wait below only protects the staging buffer; no other host sync orders copy_in)
+                up_done[s].synchronize()
             self.x_pin[s][:hi - lo].copy_(torch.from_numpy(images_u8[lo:hi]))       # host gather into pinned memory
             with torch.cuda.stream(self.copy_in):
                 if i >= 2:

@@ -4,9 +4,17 @@
 
 Workers are SPAWNED (fresh interpreters: safe next to a process that already holds a GPU context) and import only
 numpy + the native ``liboct_minpath.so`` -- never torch.  Results are exactly ``segment_maps`` of the same inputs, in
-input order."""
+input order.
+
+Spawned workers re-import ``__main__``: a script that calls ``evaluate_model`` / ``predict`` at top level without an
+``if __name__ == "__main__":`` guard would re-run itself in every worker and the parent would wait forever.  So: the
+pool is only started from a real main process (inside a spawned child the work runs inline), worker start-up is probed
+once with a timeout (workers that cannot start -- no guard, ``liboct_minpath.so`` not loadable -- make the pool fall
+back to inline execution with a warning instead of hanging), ``get()`` of a batch has a timeout with the same inline
+fallback, and under ``torchrun`` the default worker count is divided by LOCAL_WORLD_SIZE."""
 from __future__ import annotations
 
+import logging
 import multiprocessing as mp
 import os
 from typing import List, Optional, Sequence, Tuple
@@ -15,7 +23,10 @@ import numpy as np
 
 from . import graph_search
 
+log = logging.getLogger(__name__)
 _graph = None
+START_TIMEOUT_S = float(os.environ.get("OCT_GS_POOL_START_TIMEOUT", "60"))     # worker start-up probe
+TASK_TIMEOUT_S = float(os.environ.get("OCT_GS_POOL_TASK_TIMEOUT", "600"))       # one batch of maps
 
 
 def _worker_init(shape_t: Tuple[int, ...], gsgrad: int) -> None:
@@ -35,7 +46,20 @@ def default_workers() -> int:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(16, n))                                           # a GPU box's CPU share for one GPU is 16
+    n = max(1, min(16, n))                                              # a GPU box's CPU share for one GPU is 16
+    try:                                                                # one pool per rank: share the cores
+        n = max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    except ValueError:
+        pass
+    return n
+
+
+def _probe(_):
+    return os.getpid()
+
+
+def _in_spawned_child() -> bool:
+    return mp.current_process().name != "MainProcess" or mp.parent_process() is not None
 
 
 class SegmentPool:
@@ -47,10 +71,20 @@ class SegmentPool:
         self.gsgrad = int(gsgrad)
         self.workers = default_workers() if workers is None else int(workers)
         self._pool = None
+        if self.workers > 1 and _in_spawned_child():
+            log.warning("SegmentPool created inside a worker process: running the min-path post-process inline")
+            self.workers = 1
         if self.workers > 1:
-            self._pool = mp.get_context("spawn").Pool(self.workers, initializer=_worker_init,
-                                                      initargs=(self.shape_t, self.gsgrad))
-        else:
+            pool = mp.get_context("spawn").Pool(self.workers, initializer=_worker_init, initargs=(self.shape_t, self.gsgrad))
+            try:                        # workers that die while bootstrapping are respawned forever: find out now
+                pool.map_async(_probe, range(self.workers)).get(timeout=START_TIMEOUT_S)
+                self._pool = pool
+            except Exception as e:      # mp.TimeoutError, or the initializer's own error
+                pool.terminate(); pool.join()
+                log.warning("min-path worker pool did not start (%s: %s) -- is the calling script guarded by "
+                            "`if __name__ == '__main__':`? -- running inline", type(e).__name__, e)
+                self.workers = 1
+        if self._pool is None:
             _worker_init(self.shape_t, self.gsgrad)
 
     def segment_async(self, maps: np.ndarray, truths: Optional[np.ndarray] = None):
@@ -59,7 +93,7 @@ class SegmentPool:
             res = [_segment_one(t) for t in tasks]
             return _Done(res)
         chunk = max(1, len(tasks) // (4 * self.workers))
-        return self._pool.map_async(_segment_one, tasks, chunksize=chunk)
+        return _Pending(self, self._pool.map_async(_segment_one, tasks, chunksize=chunk), tasks)
 
     def segment(self, maps: np.ndarray, truths: Optional[np.ndarray] = None) -> List[Tuple[np.ndarray, np.ndarray]]:
         return self.segment_async(maps, truths).get()
@@ -79,3 +113,19 @@ class SegmentPool:
 class _Done:
     def __init__(self, res): self._res = res
     def get(self, timeout=None): return self._res
+
+
+class _Pending:
+    """A batch in flight on the pool; ``get`` falls back to inline execution if the pool does not answer in time."""
+
+    def __init__(self, owner: SegmentPool, handle, tasks):
+        self._owner, self._h, self._tasks = owner, handle, tasks
+
+    def get(self, timeout: Optional[float] = None):
+        try:
+            return self._h.get(timeout=TASK_TIMEOUT_S if timeout is None else timeout)
+        except mp.TimeoutError:
+            log.warning("min-path worker pool did not answer within the timeout: finishing this batch inline")
+            if _graph is None:
+                _worker_init(self._owner.shape_t, self._owner.gsgrad)
+            return [_segment_one(t) for t in self._tasks]

@@ -20,9 +20,18 @@ def env_rank() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+_forced = False      # a process group exists although world_size == 1 (RCCL rehearsal on one GPU)
+
+
+def init(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
+    """Join the process group named by the torchrun environment.  ``force`` (or OCT_FORCE_COLLECTIVE=1): create the
+    group even when WORLD_SIZE is 1 -- a one-rank RCCL communicator, so that the exchange step of a training step
+    (``GradReducer``: tail event -> side-stream all-reduce -> encoder-segment all-reduce -> join) runs through RCCL on
+    a single GPU exactly as it does on eight."""
+    global _forced
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("OCT_FORCE_COLLECTIVE") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -30,7 +39,34 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        _forced = world == 1
     return rank, local_rank, world
+
+
+def shutdown() -> None:
+    global _forced
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    _forced = False
+
+
+def collective_active() -> bool:
+    """True when gradient exchange goes through ``torch.distributed``: more than one rank, or a forced one-rank group."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _forced)
+
+
+def describe() -> dict:
+    """What the collective library itself reports (for the bench record): backend, world size, and every rank's device."""
+    if not dist.is_initialized():
+        return {"backend": None, "world_size": 1, "ranks": []}
+    me = {"rank": dist.get_rank(), "local_rank": env_rank()[1]}
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(i)
+        me.update(device=f"cuda:{i}", gpu=pr.name, uuid=str(getattr(pr, "uuid", "")), pci_bus_id=getattr(pr, "pci_bus_id", None))
+    ranks = [None] * dist.get_world_size()
+    dist.all_gather_object(ranks, me)
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks}
 
 
 def world_size() -> int:
@@ -118,27 +154,43 @@ class GradReducer:
 
     def __init__(self, engine, overlap: bool = True):
         self.engine = engine
-        self.overlap = bool(overlap) and world_size() > 1
+        self.active = collective_active()
+        self.overlap = bool(overlap) and self.active
         if self.overlap:
             self.side = torch.cuda.Stream(device=engine.device)
             self.event = torch.cuda.Event()
             self.off = engine.grad_tail_offset()
             engine.set_tail_event(self.event)
 
-    def backward_and_reduce(self, labels: torch.Tensor, macro: bool = True, loss_scale: float = 1.0) -> None:
+    def backward_and_reduce(self, labels: torch.Tensor, macro: bool = True, loss_scale: float = 1.0, timed: bool = False):
+        """``timed``: return [(start, end) event pairs] of the collectives issued (tail segment first), else None."""
         eng = self.engine
         eng.backward(labels, macro=macro, loss_scale=loss_scale)
-        if world_size() == 1:
-            return
-        if not self.overlap:
-            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
-            return
+        if not self.active:
+            return None
         main = torch.cuda.current_stream(eng.device)
+
+        def ev(stream):
+            e = torch.cuda.Event(enable_timing=True); e.record(stream); return e
+        pairs = []
+        if not self.overlap:
+            a = ev(main) if timed else None
+            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+            if timed:
+                pairs.append((a, ev(main)))
+            return pairs if timed else None
         self.side.wait_event(self.event)            # GPU-side: the tail segment is final
         with torch.cuda.stream(self.side):
+            a = ev(self.side) if timed else None
             dist.all_reduce(eng.grads[self.off:], op=dist.ReduceOp.SUM)
+            if timed:
+                pairs.append((a, ev(self.side)))
+        a = ev(main) if timed else None
         dist.all_reduce(eng.grads[:self.off], op=dist.ReduceOp.SUM)      # encoder segment, after the whole backward
+        if timed:
+            pairs.append((a, ev(main)))
         main.wait_stream(self.side)                 # the optimizer step needs both
+        return pairs if timed else None
 
     def close(self) -> None:
         if self.overlap:

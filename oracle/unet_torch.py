@@ -32,9 +32,11 @@ def _conv_same(x, kernel_hwio, bias):
 
 def forward(cfg: UNetConfig, params: List[dict], state: List[dict], x_nhwc: torch.Tensor,
             training: bool = False, dropout_mask: Optional[torch.Tensor] = None,
-            collect_stats: Optional[list] = None):
+            collect_stats: Optional[list] = None, collect_z: Optional[list] = None):
     """params/state: lists of dicts of torch tensors (same structure as the numpy
-    oracle).  Returns probabilities NHWC."""
+    oracle).  Returns probabilities NHWC.  ``collect_z``: every conv block's pre-BN
+    output z (NCHW) is appended, with its gradient retained -- after ``backward()``
+    ``z.grad`` is that block's dz."""
     plan = build_plan(cfg)
     x = x_nhwc.permute(0, 3, 1, 2)
     outs = {}
@@ -48,6 +50,10 @@ def forward(cfg: UNetConfig, params: List[dict], state: List[dict], x_nhwc: torc
         elif spec.src == "concat":
             x = torch.cat([x, outs[spec.skip_from]], dim=1)
         z = _conv_same(x, p["kernel"], p["bias"])
+        if collect_z is not None:
+            if z.requires_grad:
+                z.retain_grad()
+            collect_z.append(z)
         if spec.has_bn:
             st = state[bi]; bi += 1
             if training:

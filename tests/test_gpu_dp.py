@@ -5,7 +5,7 @@ A one-GPU box cannot host two RCCL ranks, so the two ranks of this test share cu
 (the collective is ``torch.distributed`` either way; ``parallel.py`` is backend-agnostic).  What is checked:
 
 * the reduced gradient of a 2-rank step (per-rank batch halves, per-rank BN statistics, per-rank dropout stream, loss
-  scaled by 1/2, tail segment all-reduced on the side stream behind the engine's event, head segment after backward)
+  scaled by 1/2, tail segment all-reduced on the side stream behind the engine's event, encoder segment after backward)
   equals the sum of the two half-batch gradients computed by ONE process with the same engines;
 * ``Model.fit`` under 2 ranks leaves bit-identical parameters on both ranks after several optimizer steps, and the
   ranks consumed disjoint halves of the same global batches.
@@ -110,3 +110,68 @@ def test_two_rank_step_equals_sum_of_half_batch_gradients_and_fit_keeps_ranks_in
     assert np.array_equal(r0["params"], r1["params"])
     assert np.array_equal(r0["hist"], r1["hist"]) and np.isfinite(r0["hist"]).all() and len(r0["hist"]) == 2
     assert not np.array_equal(r0["state"], r1["state"])                # BN moving statistics stay per replica
+
+
+def _rccl_one_rank(port, q):
+    """Child process: a ONE-rank RCCL communicator (backend "nccl" = RCCL on ROCm) driving the exchange step."""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        import torch.distributed as dist
+        from oct_image_segmentation_models_amd import parallel
+        from oct_image_segmentation_models_amd.engine import UNetEngine
+        parallel.init("nccl", force=True)
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        assert parallel.collective_active()
+        info = parallel.describe()
+        images, labels = on.synth_scans(G, H, W, C, seed=3)
+        x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+        out = {}
+        for mode in ("plain", "flat", "overlap"):
+            eng = UNetEngine(device="cuda:0", max_batch=G, training=True, seed=1000, init_seed=0, **CFG)
+            eng.set_dropout_step(5)
+            eng.forward(x, training=True, labels=lab, want_probs=False); eng.loss_dice()
+            if mode == "plain":
+                eng.backward(lab, macro=True, loss_scale=1.0)                 # no collective at all
+            else:
+                red = parallel.GradReducer(eng, overlap=(mode == "overlap"))
+                assert red.active and red.overlap == (mode == "overlap")
+                red.backward_and_reduce(lab, macro=True, loss_scale=1.0)      # RCCL all-reduce(s) of the flat buffer
+                red.close()
+            torch.cuda.synchronize()
+            out[mode] = eng.grads.cpu().numpy().copy()
+        # a timed loop: the two collectives per step really run, step after step, on their streams
+        eng = UNetEngine(device="cuda:0", max_batch=G, training=True, seed=1000, init_seed=0, **CFG)
+        red = parallel.GradReducer(eng, overlap=True)
+        for _ in range(5):
+            eng.forward(x, training=True, labels=lab, want_probs=False); eng.loss_dice()
+            red.backward_and_reduce(lab, macro=True, loss_scale=1.0); eng.adam_step(lr=1e-3)
+        torch.cuda.synchronize()
+        ok = bool(torch.isfinite(eng.params).all())
+        parallel.shutdown()
+        q.put(("ok", info, out, ok))
+    except Exception as e:       # noqa: BLE001  -- reported to the parent
+        import traceback
+        q.put(("error", traceback.format_exc(), None, False))
+
+
+def test_rccl_exchange_step_runs_on_one_gpu():
+    """SURVEY 8 row a14 / 8e.  RCCL itself, not gloo: ``init_process_group("nccl", world_size=1)`` on the one GPU of this
+    box, then the exchange step exactly as the 8-GPU run issues it -- tail event -> all-reduce of grads[off:] on the side
+    stream -> all-reduce of grads[:off] -> join.  A one-rank SUM all-reduce is the identity: gradients must equal the
+    no-collective backward BIT FOR BIT, with and without the overlap."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank, args=(_free_port(), q))
+    p.start()
+    try:
+        status, info, out, ok = q.get(timeout=300)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert status == "ok", info
+    assert info["backend"] == "nccl" and info["world_size"] == 1 and info["ranks"][0]["device"] == "cuda:0", info
+    assert np.abs(out["plain"]).max() > 0 and np.isfinite(out["plain"]).all()
+    assert np.array_equal(out["plain"], out["flat"]) and np.array_equal(out["plain"], out["overlap"])
+    assert ok

@@ -1,6 +1,7 @@
 """BASELINE batch sizes on the GPU: configs[1] is timed at batch 32 and configs[4] at batch 128, so
-the kernel variants those grids select are exercised here at exactly those sizes, through size-independent properties
-(the oracle cannot run 32 full-size scans in seconds):
+the kernel variants those grids select are exercised here at exactly those sizes: against the fp64 torch oracle
+(``test_bench_configuration_matches_the_fp64_oracle``: the numpy oracle cannot run 32 full-size scans in seconds, the
+multi-threaded torch one can) and through size-independent properties:
 
 * training step, B=32, 256x512: finite loss and gradients; the device Dice losses equal the closed forms evaluated on
   the returned probabilities; gradient buffer deterministic across two identical steps; kernel selection logged;
@@ -104,3 +105,139 @@ def test_inference_at_batch_128_graph_replay_equals_chunked_forwards():
     tie = (srt[..., -1] - srt[..., -2]) < 1e-6
     assert torch.equal(gam.long()[~tie], full.argmax(-1)[~tie])
     assert torch.isfinite(full).all() and (full.sum(-1) - 1).abs().max() < 1e-5
+
+
+
+def test_bench_configuration_matches_the_fp64_oracle():
+    """BASELINE configs[1] exactly as ``bench.py`` times it -- 256x512x1, pool_layers 4, 3 classes, batch 32, fp32,
+    default options (so: the grid-size dependent kernel selection, persistent block counts and statistic-row counts of
+    B = 32) -- against ``oracle/unet_torch.py`` in fp64 (reference: training/training.py:401-407).  Forward: every
+    layer's pre-BN output z and the loss.  Backward: every layer's dz from the head downwards and every gradient tensor.
+    An fp32 path can only differ from an fp64 one at ReLU kinks (|BN pre-activation| below fp32 rounding flips a mask
+    and the flip spreads over a few pixels per layer), so backward tensors are gated by quantiles: at least 99.9 % of the
+    elements within 5e-4 of the tensor's scale and a kernel-gradient relative L2 error of at most 1e-3."""
+    from oct_image_segmentation_models_amd.engine import UNetEngine
+    from oracle import unet_torch as ot
+    B, P = 32, 4
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    cfg = on.UNetConfig(num_classes=C, start_neurons=8, pool_layers=P)
+    params, state = on.init_params(cfg, seed=7, dtype=np.float32, randomize_bn=True)
+    eng = UNetEngine(device="cuda:0", input_channels=1, num_classes=C, image_height=H, image_width=W, max_batch=B,
+                     training=True, seed=5, init_seed=1)
+    eng.set_weights(on.keras_weight_list(params, state))
+    img, lab = scans(B, 31)
+    for k in range(B):
+        img[k] = np.roll(img[k], 5 * k, axis=1); lab[k] = np.roll(lab[k], 5 * k, axis=1)     # 32 distinct scans
+    x = torch.from_numpy(img).cuda(); l = torch.from_numpy(lab[..., 0].copy()).cuda()
+    eng.set_dropout_step(3)
+    mask = eng.dropout_mask(B).cpu().numpy().astype(np.float64)
+    eng.forward(x, training=True, labels=l, want_probs=False)
+    loss4 = eng.loss_dice().cpu().numpy()
+    eng.backward(l, macro=True, loss_scale=1.0)
+    g = eng.grads.cpu().numpy().astype(np.float64)
+    nb = len(eng.layers) - 1
+
+    # ---- the oracle: one fp64 forward + autograd backward over the same 32 scans ----
+    tp, ts = ot.to_torch(params, state, dtype=torch.float64, requires_grad=True)
+    zs = []
+    probs = ot.forward(cfg, tp, ts, torch.tensor(on.preprocess_u8(img, np.float64)), training=True,
+                       dropout_mask=torch.tensor(mask), collect_z=zs)
+    y = torch.nn.functional.one_hot(torch.tensor(lab[..., 0].astype("int64")), C).double()
+    loss = ot.dice_loss(y, probs, macro=True)
+    loss.backward()
+    assert abs(float(loss4[0]) - float(loss)) < 1e-5, (float(loss4[0]), float(loss))
+
+    # forward, per layer
+    for li in range(nb):
+        zr = zs[li].detach().permute(0, 2, 3, 1).numpy()
+        z = eng.debug_activation(li, 0)[:B].cpu().numpy()
+        err = np.abs(z - zr).max() / np.abs(zr).max()
+        assert err < 1e-4, f"layer {li} {eng.layers[li]['name']}: z differs by {err:.2e} of its scale"
+    # backward, per layer from the head downwards
+    worst_q = 0.0
+    for li in range(nb - 1, -1, -1):
+        dzr = zs[li].grad.permute(0, 2, 3, 1).numpy()
+        dz = eng.debug_dz(li)[:B].cpu().numpy()
+        scale = np.abs(dzr).max()
+        bad = float((np.abs(dz - dzr) > 5e-4 * scale).mean())
+        worst_q = max(worst_q, bad)
+        assert bad <= 1e-3, f"layer {li} {eng.layers[li]['name']}: {bad:.2e} of dz beyond 5e-4 of its scale"
+        assert np.linalg.norm(dz - dzr) <= 2e-3 * np.linalg.norm(dzr), eng.layers[li]["name"]
+    # every gradient tensor
+    for L_, p_ in zip(eng.layers, tp):
+        n = L_["kh"] * L_["kw"] * L_["cin"] * L_["cout"]; c = L_["cout"]
+        gk, rk = g[L_["kernel_off"]:L_["kernel_off"] + n], p_["kernel"].grad.numpy().ravel()
+        assert np.linalg.norm(gk - rk) <= 1e-3 * np.linalg.norm(rk), f"{L_['name']}.kernel"
+        kscale = np.abs(rk).max()
+        pieces = [("bias", L_["bias_off"])] + ([("gamma", L_["gamma_off"]), ("beta", L_["beta_off"])] if L_["has_bn"] else [])
+        for key, off in pieces:
+            rv = p_[key].grad.numpy().ravel()
+            # a conv bias ahead of a BN has an analytically zero gradient: judge it on the kernel's scale
+            scale = max(np.abs(rv).max(), kscale if key == "bias" else 0.0, 1e-12)
+            assert np.abs(g[off:off + c] - rv).max() <= 1e-3 * scale, f"{L_['name']}.{key}"
+    print(f"B=32 oracle parity: loss {float(loss4[0]):.6f} vs {float(loss):.6f}; worst dz outlier fraction {worst_q:.2e}")
+
+
+def _bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).double().numpy()
+
+
+def _bf16_ulp(a):
+    return 2.0 ** (np.floor(np.log2(np.maximum(np.abs(a), 1e-30))) - 7)
+
+
+def test_configs2_bf16_at_batch_64_full_size():
+    """BASELINE configs[2] at its size: 512x1024x1, pool_layers 5, batch 64, bf16 activations + MFMA operands with fp32
+    accumulation / BN statistics / parameters.  Properties (finite, closed-form Dice on the returned probabilities,
+    every tensor gets a gradient, two identical steps give identical bits) plus the layer-local "one bf16 rounding" check
+    on two sampled layers: the stored z of a layer recomputed in fp64 from the STORED input tensor under the
+    bf16-operand model (activation and weights rounded once, exact products, wide accumulation)."""
+    from oct_image_segmentation_models_amd.common.synthetic import make_scans
+    from oct_image_segmentation_models_amd.engine import UNetEngine
+    B, Hc, Wc, P = 64, 512, 1024, 5
+    eng = UNetEngine(device="cuda:0", input_channels=1, num_classes=C, image_height=Hc, image_width=Wc, max_batch=B,
+                     training=True, seed=5, init_seed=2, pool_layers=P, dtype="bfloat16")
+    img8, lab8 = make_scans(8, Hc, Wc, C, seed=41)
+    img = np.concatenate([np.roll(img8, 9 * k, axis=2) for k in range(B // 8)]); lab = np.concatenate([np.roll(lab8, 9 * k, axis=2) for k in range(B // 8)])
+    x = torch.from_numpy(img).cuda(); l = torch.from_numpy(lab[..., 0].copy()).cuda()
+    eng.set_dropout_step(2)
+    probs, _ = eng.forward(x, training=True, labels=l)
+    loss4 = eng.loss_dice().cpu().numpy()
+    eng.backward(l, macro=True)
+    g1 = eng.grads.clone()
+    assert torch.isfinite(probs).all() and (probs.sum(-1) - 1).abs().max() < 1e-5
+    y = torch.nn.functional.one_hot(l.long(), C).double(); pd = probs.double()
+    I = (y * pd).sum(dim=(1, 2)); D = y.sum(dim=(1, 2)) + pd.sum(dim=(1, 2))
+    assert abs(float(1 - ((2 * I + 1e-5) / (D + 1e-5)).mean()) - float(loss4[0])) < 1e-5
+    g = g1.cpu().numpy()
+    assert np.isfinite(g).all()
+    for L_ in eng.layers:
+        n = L_["kh"] * L_["kw"] * L_["cin"] * L_["cout"]
+        assert np.abs(g[L_["kernel_off"]:L_["kernel_off"] + n]).max() > 0, L_["name"]
+
+    # ---- layer-local: z of a SRC_PREV layer from the stored z of its predecessor, on a crop of one image ----
+    wl = eng.get_weights()
+    kernels, k = {}, 0
+    for li, L_ in enumerate(eng.layers):
+        kernels[li] = (wl[k], wl[k + 1]); k += 6 if L_["has_bn"] else 2
+    names = [L_["name"] for L_ in eng.layers]
+    for name, b, y0, x0 in (("enc0.conv1", 5, 100, 300), (f"dec{P - 1}.conv1", 37, 8, 640)):
+        li = names.index(name); hh, ww = 24, 40
+        zp = eng.debug_activation(li - 1, 0)[b, y0 - 1:y0 + hh + 1, x0 - 1:x0 + ww + 1].cpu().double().numpy()
+        rec = eng.debug_bn_record(li - 1).cpu().numpy()
+        a32 = np.maximum(rec[0] * zp.astype(np.float32) + rec[1], np.float32(0))        # the consumer's relu(a z + b), fp32
+        act = _bf16_round(a32)
+        w = _bf16_round(kernels[li][0]); bias = kernels[li][1].astype(np.float64)
+        zr = np.zeros((hh, ww, w.shape[3]))
+        for ky in range(3):
+            for kx in range(3):
+                zr += np.einsum("yxc,cm->yxm", act[ky:ky + hh, kx:kx + ww], w[ky, kx])
+        zr += bias
+        zh = eng.debug_activation(li, 0)[b, y0:y0 + hh, x0:x0 + ww].cpu().double().numpy()
+        d = np.abs(zh - _bf16_round(zr)); ulp = _bf16_ulp(zr)
+        assert (d <= ulp).mean() >= 0.999 and (d == 0).mean() >= 0.98, (name, float((d <= ulp).mean()), float((d == 0).mean()))
+
+    # ---- the same step again: identical bits ----
+    eng.set_dropout_step(2)
+    eng.forward(x, training=True, labels=l, want_probs=False); eng.loss_dice(); eng.backward(l, macro=True)
+    assert torch.equal(eng.grads, g1)

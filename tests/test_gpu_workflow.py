@@ -172,3 +172,44 @@ def test_batched_pipeline_equals_per_image_path_at_batch_128():
         for i in range(6):
             p_inline, e_inline, _ = graph_search.segment_maps(np.transpose(got_map[i], (0, 2, 1)), None, grid)
             assert np.array_equal(res[i][0], p_inline) and np.array_equal(res[i][1], e_inline)
+
+
+def test_config0_at_its_stated_size(tmp_path):
+    """BASELINE configs[0] as written: 4 train (+ 4 validation) 256x512x1 scans in a real HDF5 file, 3 boundaries
+    (= 4 classes), 1 epoch through ``train_model`` (reference training/training.py:135-408) -- the plumbing case,
+    checked against the output-file contract of SURVEY 8(a')."""
+    import json
+    from oct_image_segmentation_models_amd import optimizers
+    from oct_image_segmentation_models_amd.common import h5io
+    from oct_image_segmentation_models_amd.training.training import train_model
+    from oct_image_segmentation_models_amd.training.training_parameters import TrainingParams
+    Hc, Wc, Cc = 256, 512, 4
+    tr_i, tr_l = on.synth_scans(4, Hc, Wc, Cc, seed=11)
+    va_i, va_l = on.synth_scans(4, Hc, Wc, Cc, seed=12)
+    assert tr_i.shape == (4, Hc, Wc, 1) and tr_i.dtype == np.uint8 and sorted(np.unique(tr_l)) == [0, 1, 2, 3]
+    data = tmp_path / "config0.hdf5"
+    h5io.save(data, {"train_images": tr_i, "train_labels": tr_l, "val_images": va_i, "val_labels": va_l})
+    assert data.exists() and open(data, "rb").read(8) == b"\x89HDF\r\n\x1a\n"          # a real HDF5 container
+    tp = TrainingParams(model_architecture="unet", training_dataset_path=data, initial_model=None,
+                        results_location=tmp_path / "results", opt_con=optimizers.Adam, opt_params={"learning_rate": 1e-3},
+                        loss="dice_loss_macro", metric="dice_coef_macro", epochs=1, batch_size=4, seed=3)
+    res = train_model(tp, None)
+    d = Path(res.save_foldername)
+    assert d.parent == tmp_path / "results" and d.name.endswith("_unet")
+    cfg = json.load(open(d / "model_config.json"))
+    assert (cfg["num_classes"], cfg["image_height"], cfg["image_width"], cfg["input_channels"]) == (Cc, Hc, Wc, 1)
+    assert cfg.get("start_neurons", 8) == 8 and cfg.get("pool_layers", 4) == 4           # the reference's defaults
+    tpf = h5io.load(d / "training_params.hdf5")
+    assert bytes(tpf["attr:loss_name"]).rstrip(b"\x00") == b"dice_loss_macro" and tpf["attr:batch_size"] == 4
+    assert tpf["attr:epochs"] == 1 and bytes(tpf["attr:optimizer"]).rstrip(b"\x00") == b"Adam"
+    hist = res.history
+    assert set(hist) == {"loss", "dice_coef_macro", "val_loss", "val_dice_coef_macro"} and len(hist["loss"]) == 1
+    assert all(np.isfinite(v[0]) for v in hist.values()) and 0.0 < hist["loss"][0] < 1.0
+    stats = h5io.load(d / "stats_epoch01.hdf5")
+    assert set(stats) >= {"train_acc", "val_acc", "train_loss", "val_loss", "epoch_time"} and len(stats["train_loss"]) == 1
+    assert len(res.checkpoints) == 1 and Path(res.checkpoints[0]).name.startswith("model_epoch01")
+    # the checkpoint loads back into a model that predicts (n, H, W, 4) probabilities
+    from oct_image_segmentation_models_amd.models.engine_model import load_model
+    m = load_model(res.checkpoints[0])
+    p = m.predict(va_i[:2].astype(np.float32) / 255.0, batch_size=2)
+    assert p.shape == (2, Hc, Wc, Cc) and np.abs(p.sum(-1) - 1).max() < 1e-5

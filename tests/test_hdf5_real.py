@@ -128,3 +128,34 @@ def test_files_written_here_are_read_by_the_real_h5py(tmp_path):
     from oct_image_segmentation_models_amd.models.engine_model import load_model
     m = load_model(kp)
     assert all(np.array_equal(a, b) for a, b in zip(m.get_weights(), w))
+
+
+def test_h5lite_reads_shape_dtype_and_leading_axis_ranges_without_reading_the_dataset():
+    """``Dataset.shape`` / ``.dtype`` / ``len`` come from the file's metadata and a contiguous range of the leading axis is
+    read as an HDF5 hyperslab (what the batch generators do on multi-GB ``train_images``): checked on the file the REAL
+    h5py wrote, against its expected arrays."""
+    from oct_image_segmentation_models_amd.common import h5lite
+    if not h5lite.available():
+        pytest.skip("libhdf5 not loadable")
+    exp = expected()
+    with h5lite.File(os.path.join(GOLD, "dataset_small.hdf5"), "r") as f:
+        d = f["train_images"]; e = exp["train_images"]
+        reads = []
+        orig = h5lite._read
+
+        def spy(*a, **k):
+            out = orig(*a, **k); reads.append(np.shape(out)); return out
+        h5lite._read = spy
+        try:
+            assert d.shape == e.shape and d.dtype == e.dtype and len(d) == e.shape[0]
+            assert reads == []                                            # metadata only
+            assert np.array_equal(d[1:3], e[1:3]) and reads[-1] == e[1:3].shape      # only the two scans left the file
+            assert np.array_equal(d[-1], e[-1]) and reads[-1] == e[-1:].shape
+            assert np.array_equal(d[0:2, ...], e[0:2]) and d[2:2].shape == (0,) + e.shape[1:]
+            assert np.array_equal(d[::2], e[::2]) and np.array_equal(d[1:, 3], e[1:, 3]) and np.array_equal(d[()], e)
+            with pytest.raises(IndexError):
+                d[e.shape[0]]
+        finally:
+            h5lite._read = orig
+        names = f["test_images_source"]
+        assert names.dtype == np.dtype("O") or names.dtype.kind == "S"

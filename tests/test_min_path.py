@@ -101,3 +101,28 @@ def test_segment_pool_equals_inline_segment_maps():
             assert np.array_equal(g[i][0], want[i][0]) and np.array_equal(g[i][1], want[i][1], equal_nan=True)
         assert np.array_equal(want[i][0][0], truths[i, 0].astype(np.uint16))   # the bright ridge is found
     assert np.array_equal(got_async[1][0], want[1][0])
+
+
+def test_pool_started_from_an_unguarded_script_falls_back_inline_instead_of_hanging(tmp_path):
+    """Spawned workers re-import ``__main__``; a top-level script without the ``__main__`` guard (here: a script fed on
+    stdin, which a worker cannot even open) can never bring a worker up.  The pool must notice (start-up probe with a
+    timeout), say so, and run the post-process inline -- same results."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import oct_image_segmentation_models_amd\n"
+        "from oct_image_segmentation_models_amd.min_path_processing.pool import SegmentPool\n"
+        "maps = np.zeros((3, 2, 24, 40), np.uint8); maps[:, 0, 7, :] = 255; maps[:, 1, 15, :] = 255\n"
+        "p = SegmentPool((24, 40), workers=2)\n"
+        "r = p.segment(maps)\n"
+        "print('WORKERS', p.workers, 'ROWS', r[0][0][:, 0].tolist(), flush=True)\n"
+        "p.close()\n")
+    env = dict(os.environ, OCT_GS_POOL_START_TIMEOUT="5")
+    out = subprocess.run([sys.executable, "-"], input=code.encode(), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                         env=env, timeout=120)
+    assert out.returncode == 0
+    assert b"WORKERS 1 ROWS [7, 15]" in out.stdout, out.stdout[-300:]

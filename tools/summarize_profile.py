@@ -7,6 +7,9 @@
                                     half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section)
   profiles/<tag>_bench.json         the bench line of the same run
   profiles/<tag>_launch_table.json  per-(kernel, layer) HIP-event durations + algorithmic flops/bytes (library profiler)
+  profiles/<tag>_sq_counters.json   per kernel (and family): matrix-pipe busy share, VALU / MFMA instruction counts, wait
+                                    shares, LDS bank conflicts from the two SQ --pmc passes (train steps only)
+  profiles/<tag>_infer_kernel_stats.csv   the same --stats summary for the hipGraph-replayed batch-128 inference forward
 """
 import collections
 import csv
@@ -75,6 +78,51 @@ if pmc_steps:
 json.dump(doc, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 if pmc_steps:
     print(f"train-step HBM traffic: {total / pmc_steps / 1e9:.2f} GB/step over {pmc_steps} steps")
+
+# ---- SQ counters: per kernel instantiation averages per launch, and what they say ----
+sq = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(os.path.join(src, "sq_pass*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "oct::" not in r["Kernel_Name"]:
+            continue
+        a = sq[short(r["Kernel_Name"])][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+if sq:
+    def derive(c):
+        g = lambda k: c.get(k, 0.0)
+        d = {}
+        if g("SQ_BUSY_CYCLES"):      # SQ_VALU_MFMA_BUSY_CYCLES counts cycles, summed over the SIMDs that were busy; SQ_BUSY_CYCLES per SE
+            d["mfma_busy_over_4x_sq_busy"] = round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * g("SQ_BUSY_CYCLES")), 4)
+        if g("SQ_WAVE_CYCLES"):
+            d["issue_stall_share_of_wave_cycles"] = round(g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), 4)
+            d["parked_share_of_wave_cycles"] = round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4)
+            d["issuing_share_of_wave_cycles"] = round(g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"), 4)
+        if g("SQ_INSTS_MFMA"):
+            d["valu_per_mfma_instruction"] = round(g("SQ_INSTS_VALU") / g("SQ_INSTS_MFMA"), 2)
+        if g("SQ_LDS_IDX_ACTIVE"):
+            d["lds_conflict_share_of_lds_cycles"] = round(g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE"), 4)
+        return d
+    kern = {}
+    famc = collections.defaultdict(lambda: collections.defaultdict(float)); famn = collections.defaultdict(int)
+    for k, cs in sq.items():
+        avg = {c: v[0] / max(v[1], 1) for c, v in cs.items()}
+        n = max(v[1] for v in cs.values())
+        kern[k] = {"launches_in_pass": n, "per_launch": {c: round(v, 1) for c, v in sorted(avg.items())}, "derived": derive(avg)}
+        for c, v in cs.items():
+            famc[k.split("<")[0]][c] += v[0]
+        famn[k.split("<")[0]] += n
+    fams = {k: {"launches_in_pass": famn[k], "totals": {c: round(v, 1) for c, v in sorted(cs.items())}, "derived": derive(cs)}
+            for k, cs in famc.items()}
+    json.dump({"note": "rocprofv3 --pmc (two passes of 8 SQ counters, counters + kernel trace only) over `bench.py --steps 1 --warmup 1 "
+                       "--no-inference ...`: train steps at B = 32.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles "
+                       "summed over waves, SQ_VALU_MFMA_BUSY_CYCLES cycles (MI355X_MICROARCH.md); `derived` are ratios of counters of "
+                       "the SAME pass.  Profiled runs clock lower than un-profiled ones: ratios, not absolute times.",
+               "commit": commit, "families": fams, "kernels": kern},
+              open(os.path.join(dst, f"{tag}_sq_counters.json"), "w"), indent=1)
+    print("SQ counters:", ", ".join(f"{k} mfma-busy {v['derived'].get('mfma_busy_over_4x_sq_busy')}" for k, v in fams.items()
+                                    if k in ("conv_bx_k", "conv_dwbx_k", "conv_bt_k", "conv_dwbt_k")))
+inf = glob.glob(os.path.join(src, "trace_infer", "*", "*_kernel_stats.csv"))
+if inf:
+    shutil.copy(max(inf, key=os.path.getmtime), os.path.join(dst, f"{tag}_infer_kernel_stats.csv"))
 
 rows = list(csv.DictReader(open(stats)))
 print(f"{'kernel':52s} {'calls':>6s} {'avg_us':>9s} {'total_ms':>9s} {'%':>6s} {'HBM MB/launch':>14s}")
