@@ -153,8 +153,9 @@ def fit_throughput(eng, H, W, C, P, B, n_scans, resident_scans_per_s):
     mc = get_model_class("unet")(input_channels=1, num_classes=C, image_height=H, image_width=W, pool_layers=P)
     model = mc.build_model()
     model._device = str(eng.device)
-    model.compile(optimizer=optimizers.Adam(learning_rate=1e-3), loss=custom_losses.custom_loss_objects["dice_loss_macro"],
-                  metrics=[custom_metrics.training_monitor_metric_objects["dice_coef_macro"]])
+    loss_fn = custom_losses.custom_loss_objects["dice_loss_macro"]["function"](num_classes=C, is_y_true_sparse=False)
+    metric_fn = custom_metrics.training_monitor_metric_objects["dice_coef_macro"](False, C)
+    model.compile(optimizer=optimizers.Adam(learning_rate=1e-3), loss=loss_fn, metrics=[metric_fn])
     gen = DataGenerator(images, labels, B, [], "none", (), False, mc.get_preprocess_input_fn(), seed=5)
     warm = DataGenerator(images[:4 * B], labels[:4 * B], B, [], "none", (), False, mc.get_preprocess_input_fn(), seed=5)
     model.fit(x=warm, epochs=1, verbose=0)

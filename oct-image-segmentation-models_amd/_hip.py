@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboct_unet_hip.so")
+LIB_PATH = os.environ.get("OCT_UNET_LIB") or os.path.join(_HERE, "liboct_unet_hip.so")     # (OCT_UNET_LIB: kernel experiments)
 
 
 class OctError(RuntimeError):

@@ -27,9 +27,11 @@ struct Options {
     int pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW
     int pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
     int dw_side_stream = 1;         // backward-weights kernels on the handle's side stream beside the backward-data chain
+    int bx_two_blocks = 0;          // wide bf16-pipe launches as 4-wave blocks with one input image, two per CU (experiment)
     int bx_waves = 8;               // waves per block of conv_bx_k where the tile has >= 8 rows
     int fuse_first_apply = 1;       // the first conv's BN-backward transform is applied inside its backward-weights kernel
     int fuse_bn_apply = 1;          // every other block: the transform is applied by the dX / dW kernels while they stage g'
+    int fuse_dw_thin = 1;           // 3x3 layers with 8 output channels: backward-weights reduced inside the backward-data launches
     int timing_skip = 0;            // TIMING EXPERIMENTS ONLY (results become wrong): bit 0 / 1 = skip the forward / backward BN finalize launches after step 2
     int fuse_bn_finalize = 1;       // BN statistic partials are finalized by the last block of the producing launch
     int bt_m2 = 1;                  // conv_bt_k: 8-output-channel launches in the two-pixel form

@@ -152,8 +152,11 @@ __host__ inline size_t wbx_bytes(int KH, int Kc, int M, int MB, int NS) {
 // of its SIMD partner; each wave then owns TH / 8 pixel rows).
 // GB (backward-data launches): the input x0 is the masked gradient g' of the layer whose dX this is; the BN-backward
 // transform dz = ga g' + gb z + gd (A.gb_z, A.gb_bn; common.hpp) is applied while the tile is staged.
-template <int KH, int AMODE, int EPI, int TH, int MB, int NS, bool DROP, int NW, typename AT, bool GB = false>
-__global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
+// NIMG = 1: ONE input image instead of the double buffer -- the block then fits twice per CU (4-wave blocks): the
+// conversion of the next K chunk is no longer hidden behind this block's own MFMAs but behind the OTHER resident block's,
+// and so are this block's prologue, barriers and epilogue (two independent instruction streams per SIMD).
+template <int KH, int AMODE, int EPI, int TH, int MB, int NS, bool DROP, int NW, typename AT, bool GB = false, int NIMG = 2>
+__global__ __launch_bounds__(64 * NW, NIMG == 1 ? (NW == 4 ? 2 : 1) : 1) void conv_bx_k(const IgemmArgs A) {
     constexpr int NTHR = 64 * NW;
     constexpr int TW = 32, MTW = MB / 32, NTW = TH / NW, ACC = 16, QUADS = 4, MT = 32;
     static_assert(TH % NW == 0 && NTW >= 1 && (MB == 32 || MB == 64), "tile geometry");
@@ -174,10 +177,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
     constexpr int SCRATCH_B = (EPI_B + RED_B) > 2 * SLAB_B ? (EPI_B + RED_B) : 2 * SLAB_B;
 
     static_assert(!GB || (EPI != EPI_FWD && !DROP), "the BN-backward transform on load belongs to backward-data launches");
-    __shared__ __attribute__((aligned(1024))) char smem[2 * IN_B + SCRATCH_B + (GB ? 3 : 2) * MAXC * 4];
+    static_assert(NIMG == 1 || NIMG == 2, "one input image or a double buffer");
+    __shared__ __attribute__((aligned(1024))) char smem[NIMG * IN_B + SCRATCH_B + (GB ? 3 : 2) * MAXC * 4];
     char* const INs = smem;
-    char* const WTs = smem + 2 * IN_B;
-    float* const ABs = reinterpret_cast<float*>(smem + 2 * IN_B + SCRATCH_B);     // [2][MAXC]: a row, b row (GB: ga, gd, gb rows)
+    char* const WTs = smem + NIMG * IN_B;
+    float* const ABs = reinterpret_cast<float*>(smem + NIMG * IN_B + SCRATCH_B);     // [2][MAXC]: a row, b row (GB: ga, gd, gb rows)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -324,6 +328,17 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
         const char* Wb = WTs + slot * SLAB_B + a_lane;
         const char* Ib = INs + buf * IN_B;
         auto load_frag = [&](int kx, Frag& f) {
+#if defined(BX_DBG) && BX_DBG == 3      // timing experiment: no LDS fragment reads
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) asm volatile("" : "=v"(f.a[mt][p]));
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) asm volatile("" : "=v"(f.b[nt][p]));
+            return;
+#endif
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -344,6 +359,17 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
             }
         };
         auto mfma_tap = [&](const Frag& f) {
+#if defined(BX_DBG) && BX_DBG == 2      // timing experiment: no MFMAs (fragments kept alive)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) asm volatile("" :: "v"(f.a[mt][p]));
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) asm volatile("" :: "v"(f.b[nt][p]));
+            return;
+#endif
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -366,10 +392,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
         for (int kx = 0; kx < KH; ++kx) {
             if (kx + 1 < KH) load_frag(kx + 1, f[(kx + 1) & 1]);
             mfma_tap(f[kx & 1]);
+#if !(defined(BX_DBG) && BX_DBG == 4)      // (4: timing experiment without the in-loop conversions)
             if constexpr (decltype(do_store)::value) {
 #pragma unroll
                 for (int k = kx; k < NSLOT; k += KH) store_slot(k, sbuf);
             }
+#endif
         }
     };
 
@@ -399,17 +427,33 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_bx_k(const IgemmArgs A) {
                 }
                 begin_store((c + 1) * 16);
             }
+#if !(defined(BX_DBG) && BX_DBG == 5)      // (5: timing experiment without the in-loop weight DMA)
             if (!last_row) dma_slab(c, ky + 1, (g + 1) & 1);
             else if (more) dma_slab(c + 1, 0, (g + 1) & 1);
+#endif
             if (ky == 0 && more) load_in((c + 1) * 16);
-            if (last_row && more) sweep_row(ky, g & 1, c & 1, std::true_type{}, (c + 1) & 1);
-            else sweep_row(ky, g & 1, c & 1, std::false_type{}, 0);
+            if constexpr (NIMG == 2) {
+                if (last_row && more) sweep_row(ky, g & 1, c & 1, std::true_type{}, (c + 1) & 1);
+                else sweep_row(ky, g & 1, c & 1, std::false_type{}, 0);
+            } else {
+                sweep_row(ky, g & 1, 0, std::false_type{}, 0);
+                if (last_row && more) {          // every wave is done with the image: overwrite it with the next K chunk
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < NSLOT; ++k) store_slot(k, 0);
+                }
+            }
             // an LDS-DMA becomes visible to other waves' ds_reads only through the issuing wave's vmcnt wait followed by
             // a barrier: drain explicitly (hipcc also does before __syncthreads() while a DMA is in flight)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(defined(BX_DBG) && BX_DBG == 1)      // (1: timing experiment without the per-step barrier)
             __syncthreads();
+#endif
         }
     }
+#if defined(BX_DBG) && BX_DBG == 1
+    __syncthreads();
+#endif
 
     // ---- epilogue (same forms as conv_igemm_k; the weight slots are free now) ----
     float* const epi = reinterpret_cast<float*>(WTs);
@@ -863,9 +907,20 @@ __host__ inline size_t wbt_bytes(int KH, int CT, int NS, bool m2 = false) { retu
 
 // GB (backward-data launches): x0 is the masked gradient g' of the layer; dz = ga g' + gb z + gd is formed while the tile is
 // staged (A.gb_z, A.gb_bn; common.hpp) -- the stand-alone bn_bwd_apply pass over g' is gone.
-template <int KH, int AMODE, int EPI, int CT, int NS, typename AT, bool M2 = false, bool GB = false>
-__global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void conv_bt_k(const IgemmArgs A) {
+//
+// FDW (3x3 layers with 8 output channels -- the full-resolution convs -- backward): the launch ALSO reduces the layer's
+// backward-weights dW[tap][ci][co] = sum_q X(q)[ci] dz(q - tap + 1)[co] over its tiles, for the 8 input channels whose
+// gradient it produces.  The dz halo tile is already in LDS, split, for the backward-data MFMAs; the conv input X of the
+// tile's own pixels q (= relu(a z + b) of the producer, the tensor the mask epilogue reads anyway) is staged beside it, and
+// both reach the matrix core through transposing LDS reads (K = the 32 pixels of a tile row): A = X^T (rows = ci; rows
+// 8-15 repeat them), B = dz at two horizontally adjacent taps (columns (dx, co)): per kernel row the column pairs
+// (kx 1, kx 0) and (kx 2, -).  g', z and the producer's z then leave HBM ONCE for dX and dW together -- the separate
+// backward-weights kernel of these layers (3 more tensor passes over the largest tensors of the net) is gone.
+// One partial slab per block, like conv_dwbt_k (A.dw_part; reduce_all_k sums them); two blocks per CU.
+template <int KH, int AMODE, int EPI, int CT, int NS, typename AT, bool M2 = false, bool GB = false, bool FDW = false>
+__global__ __launch_bounds__(kBlock, FDW ? 2 : (CT == 32 ? 1 : (CT == 16 ? 2 : 3))) void conv_bt_k(const IgemmArgs A) {
     static_assert(!GB || EPI != EPI_FWD, "the BN-backward transform on load belongs to backward-data launches");
+    static_assert(!FDW || (GB && CT == 8 && KH == 3 && AMODE == A_NORMAL), "fused backward-weights: 3x3, 8 K channels, transform on load");
     static_assert(!M2 || ((CT == 8 || CT == 16) && AMODE != A_DOWN2), "two-pixel form: 8 or 16 K channels, unit-stride or upsampled input");
     constexpr int TH = 8, TW = 32, TAPS = KH * (M2 ? KH + 1 : KH), TPM = 32 / CT, NG = (TAPS + TPM - 1) / TPM, OCT = CT / 8;
     constexpr int KW = M2 ? KH + 1 : KH;                          // taps per kernel row of the (extended) window
@@ -886,8 +941,10 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
             else return (P ^ ((P >> 3) & 1)) * PIXB + ((o ^ ((P >> 4) & 1)) * 16);
         } else return P * PIXB + ((o ^ ((P >> SWS) & (OCT - 1))) * 16);
     };
-    __shared__ __attribute__((aligned(256))) char smem[2 * IN_B + (4 * MB + 4 * 2 * MB) * 4];
-    float* const epi = reinterpret_cast<float*>(smem + 2 * IN_B);     // EPI_MASK: producer's BN rows a / b / mean / rstd
+    constexpr int XPL = TH * TW * 16, XIMG_B = FDW ? NS * XPL : 0;      // FDW: the tile's own X pixels, [term][pixel][8 ch]
+    __shared__ __attribute__((aligned(256))) char smem[2 * IN_B + 2 * XIMG_B + (4 * MB + 4 * 2 * MB) * 4];
+    char* const Xs = smem + 2 * IN_B;
+    float* const epi = reinterpret_cast<float*>(smem + 2 * IN_B + 2 * XIMG_B);     // EPI_MASK: producer's BN rows a / b / mean / rstd
     float* const red = epi + 4 * MB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -939,7 +996,7 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
         sly[k] = P < NPIX ? P / IW : -1000000; slx[k] = P % IW;                 // pad pixels fall outside every image
         sdst[k] = lds_off(P, o);
     }
-    struct RegSet { typename Raw4<AT>::type v[NSLOT][2], z[GB ? NSLOT : 1][2]; };
+    struct RegSet { typename Raw4<AT>::type v[NSLOT][2], z[GB ? NSLOT : 1][2], x[FDW ? 2 : 1]; };
     auto origin = [&](const TileOrg& t, int& iy0, int& ix0) {
         const int y0 = t.ty * TH, x0 = t.tx * TW;
         iy0 = AMODE == A_NORMAL ? y0 - (KH - 1) / 2 : (AMODE == A_UPF ? y0 / 2 : 2 * y0 - 1);
@@ -972,6 +1029,12 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
         }
         return xsrc + (size_t)(t.b * A.Hi * A.Wi) * Cs;
     };
+    float xa[FDW ? 8 : 1], xb[FDW ? 8 : 1], bsum[FDW ? 8 : 1];
+    bool stage_live = true;              // false while the tile loop re-stages its last tile as a dummy (branch-free body)
+    if constexpr (FDW) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xa[i] = A.dw_ab[BN_A * A.Mout + i]; xb[i] = A.dw_ab[BN_B * A.Mout + i]; bsum[i] = 0.f; }
+    }
     auto load_item = [&](int k, const AT* ib, RegSet& RS) {
         RS.v[k][0] = ldraw4<AT>(ib + aoff[k]); RS.v[k][1] = ldraw4<AT>(ib + aoff[k] + 4);
         if constexpr (GB) { RS.z[k][0] = ldraw4<AT>(ib + zdelta + aoff[k]); RS.z[k][1] = ldraw4<AT>(ib + zdelta + aoff[k] + 4); }
@@ -985,6 +1048,11 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
             const float4 z0 = widen4(RS.z[k][0]), z1 = widen4(RS.z[k][1]);
             const float zv[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
             gb8<AT>(v, zv, fa, fz, fb, in);
+            if constexpr (FDW) {      // bias gradient = column sums of dz over the tile's OWN pixels (the halo belongs to neighbours)
+                const bool own = stage_live && sly[k] >= 1 && sly[k] <= TH && slx[k] >= 1 && slx[k] <= TW;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bsum[i] += own ? v[i] : 0.f;
+            }
         } else act8(v, fa, fb, lo, in);
         uint4 pl[NS];
         split8<NS>(v, pl);
@@ -992,15 +1060,39 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
 #pragma unroll
         for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * PLANE_B) = pl[p];
     };
+    // ---- FDW: the conv input of the tile's own pixels.  Thread t serves pixel (t >> 5, t & 31), all 8 channels ----
+    auto x_load = [&](const TileOrg& t, RegSet& RS) {          // unconditional, position clamped into the image
+        if constexpr (FDW) {
+            int gy = t.ty * TH + (tid >> 5), gx = t.tx * TW + (tid & 31);
+            gy = gy >= A.Ho ? A.Ho - 1 : gy; gx = gx >= A.Wo ? A.Wo - 1 : gx;
+            const AT* p = reinterpret_cast<const AT*>(A.dw_x) + ((size_t)(t.b * A.Ho + gy) * A.Wo + gx) * A.Mout;
+            RS.x[0] = ldraw4<AT>(p); RS.x[1] = ldraw4<AT>(p + 4);
+        }
+    };
+    auto x_store = [&](const TileOrg& t, int buf, const RegSet& RS) {
+        if constexpr (FDW) {
+            const float4 v0 = widen4(RS.x[0]), v1 = widen4(RS.x[1]);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const bool in = t.ty * TH + (tid >> 5) < A.Ho && t.tx * TW + (tid & 31) < A.Wo;
+            act8(v, xa, xb, 0.f, in);                              // relu(a z + b) inside the image, exactly 0 outside
+            uint4 pl[NS];
+            split8<NS>(v, pl);
+            char* d = Xs + buf * XIMG_B + tid * 16;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(d + p * XPL) = pl[p];
+        }
+    };
     auto load = [&](const TileOrg& t, RegSet& RS) {
         const AT* ib = addr(t);
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) load_item(k, ib, RS);
+        x_load(t, RS);
     };
     auto store = [&](const TileOrg& t, int buf, const RegSet& RS) {
         int iy0, ix0; origin(t, iy0, ix0);
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) store_item(k, iy0, ix0, buf, RS);
+        x_store(t, buf, RS);
     };
 
     // ---- per-lane B-fragment geometry: K-slice kg of group g = tap g * TPM + kg / OCT, channel octet kg % OCT ----
@@ -1033,6 +1125,21 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
         const int r = M2 ? 2 * wave + nt : 2 * wave + (nt >> 1), x = M2 ? 2 * px + dx : 16 * (nt & 1) + px;
         ooff[nt] = (r * A.Wo + x) * A.Mout + (m4 < A.Mout ? m4 : 0);
     }
+
+    // ---- FDW: accumulators (kernel row ky, column pair kb: base tap column 1 -> taps (1, 0); 2 -> (2, -)) and the lane
+    // geometry of the transposing reads: lane 4q + pp of 16-lane group kg supplies row (= pixel) 8 kg + q of a 4 x 16
+    // block, values 4 pp .. 4 pp + 3 of its 16; the two reads of a fragment are 4 pixels apart (K = 8 kg .. 8 kg + 7) ----
+    f32x4 dacc[FDW ? 6 : 1];
+    if constexpr (FDW) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) dacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int trq = (lane & 15) >> 2, trp = lane & 3;
+    const int xlane = (8 * kg + trq) * 16 + 8 * (trp & 1);                       // X image: rows 8-15 of A repeat rows 0-7
+    // dz halo-image pixel for X pixel (row 2 wave, column 8 kg + q) at tap (ky 2, kx 1): row qy + 2 - ky, column qx + 2 - kx,
+    // + 1 for the right half of the 16 values (the next pixel = tap kx - 1)
+    const int dpix = 2 * wave * IW + 8 * kg + trq + 1 + (trp >> 1);
+    auto tr4 = [](const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p)); };
 
     float s1[ACC] = {0.f, 0.f, 0.f, 0.f}, s2[ACC] = {0.f, 0.f, 0.f, 0.f};
     TileWalk<TH, TW> walk;
@@ -1069,18 +1176,45 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
         }
         const AT* const ib2 = addr(nx2);                       // item addresses of tile t+2 (the branch stays out of the MFMA block)
         int iy1, ix1; origin(nxt, iy1, ix1);                   // tile t+1 is in R0 (a dummy repeat behind the last tile: branch-free body)
+        stage_live = tl + walk.step < walk.tlend;
         f32x4 acc[NTW];
         const char* Ib = smem + buf * IN_B;
         {   // flat sequence of (pixel group, K group) steps; the B fragments of step s+2 are requested before the MFMAs of
             // step s issue (ring of 3 fragment sets): an LDS round trip is longer than the 6 MFMAs of one step.  The staging
             // items of tile t+1 (registers -> LDS, other buffer) and the loads of tile t+2 into the freed registers sit in
             // program order BEHIND the fragment reads of their step: an LDS write may not move above a read it might alias.
-            constexpr int STEPS = NTW * NG, DEPTH = 3;
-            bf16x8 bv[DEPTH][NS];
+            // FDW appends the backward-weights steps to the same sequence -- (X row r of this wave, kernel row ky, column
+            // pair kb): A = the X row's fragments, B = dz at that tap pair, both through transposing reads -- so that their
+            // LDS round trips hide behind the backward-data MFMAs and vice versa.
+            constexpr int SX = NTW * NG, SD = FDW ? 12 : 0, STEPS = SX + SD, DEPTH = 3;
+            constexpr int NITEM = NSLOT + (FDW ? 1 : 0);          // staging items: the dz slots, then the X pixel
+            bf16x8 bv[DEPTH][NS], af[FDW ? 2 : 1][NS];
+            const char* const Xb = Xs + buf * XIMG_B + xlane;
             auto fetch = [&](int st, bf16x8 (&f)[NS]) {
-                const char* q = Ib + bofs[st / NG][st % NG];
+                if (st < SX) {
+                    const char* q = Ib + bofs[st / NG][st % NG];
 #pragma unroll
-                for (int p = 0; p < NS; ++p) f[p] = *reinterpret_cast<const bf16x8*>(q + p * PLANE_B);
+                    for (int p = 0; p < NS; ++p) f[p] = *reinterpret_cast<const bf16x8*>(q + p * PLANE_B);
+                } else {
+                    // dz at pixel q - tap + 1: halo row qy + 2 - ky, halo column qx + 2 - kx (+ 1 for the right half of the 16)
+                    const int j = st - SX, r = j / 6, ky = (j % 6) / 2, kb = j % 2;
+                    const int P0 = dpix + (r + 2 - ky) * IW - kb, P1 = P0 + 4;
+                    const char* q0 = Ib + lds_off(P0, 0) + 8 * (trp & 1);
+                    const char* q1 = Ib + lds_off(P1, 0) + 8 * (trp & 1);
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) {
+                        const bf16x4 lo4 = tr4(q0 + p * PLANE_B), hi4 = tr4(q1 + p * PLANE_B);
+                        f[p] = bf16x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                    }
+                }
+            };
+            auto fetch_a = [&](int r, bf16x8 (&f)[NS]) {          // X row 2 wave + r: rows = ci (8-15 repeat 0-7), K = its 32 pixels
+#pragma unroll
+                for (int p = 0; p < NS; ++p) {
+                    const char* q = Xb + p * XPL + (2 * wave + r) * (TW * 16);
+                    const bf16x4 lo4 = tr4(q), hi4 = tr4(q + 4 * 16);
+                    f[p] = bf16x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                }
             };
             fetch(0, bv[0]);
             if (STEPS > 1) fetch(1, bv[1]);
@@ -1088,38 +1222,65 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 if (st + 2 < STEPS) fetch(st + 2, bv[(st + 2) % DEPTH]);
-                const int g = st % NG;
-                const bf16x8 (&b)[NS] = bv[st % DEPTH];
-                if constexpr (NS == 3) {
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], b[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][2], b[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][1], b[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], b[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][1], b[0], c, 0, 0, 0);
+                if constexpr (FDW) {
+                    if (st == SX - 2) fetch_a(0, af[0]);           // two steps ahead of their first use
+                    if (st == SX + 4) fetch_a(1, af[1]);
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], b[0], c, 0, 0, 0);
-                if (g == NG - 1) { acc[st / NG] = c; c = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                const bf16x8 (&b)[NS] = bv[st % DEPTH];
+                if (st < SX) {
+                    const int g = st % NG;
+                    if constexpr (NS == 3) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], b[2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][2], b[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][1], b[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], b[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][1], b[0], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g][0], b[0], c, 0, 0, 0);
+                    if (g == NG - 1) { acc[st / NG] = c; c = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                } else if constexpr (FDW) {
+                    const int j = st - SX;
+                    const bf16x8 (&xa_)[NS] = af[j / 6];
+                    f32x4 d = dacc[j % 6];
+                    if constexpr (NS == 3) {
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa_[0], b[2], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa_[2], b[0], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa_[1], b[1], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa_[0], b[1], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa_[1], b[0], d, 0, 0, 0);
+                    }
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa_[0], b[0], d, 0, 0, 0);
+                    dacc[j % 6] = d;
+                }
 #pragma unroll
-                for (int k = 0; k < NSLOT; ++k)
-                    if ((k * STEPS) / NSLOT == st) { store_item(k, iy1, ix1, buf ^ 1, R0); load_item(k, ib2, R0); }
+                for (int k = 0; k < NITEM; ++k)
+                    if ((k * STEPS) / NITEM == st) {
+                        if (k < NSLOT) { store_item(k, iy1, ix1, buf ^ 1, R0); load_item(k, ib2, R0); }
+                        else { x_store(nxt, buf ^ 1, R0); x_load(nx2, R0); }
+                    }
             }
             // pin the schedule of this basic block (hipcc otherwise sinks every LDS read next to its use and emits the
             // whole conversion in front of the MFMAs): per step the fragments two steps ahead, the step's MFMAs, a share
-            // of the conversion VALU in their shadow, and behind an item its LDS writes and the two loads that refill it
+            // of the conversion VALU in their shadow, and behind an item its LDS writes and the loads that refill it
             constexpr int NPROD = NS == 3 ? 6 : 1;
-            constexpr int VPS = (NSLOT * ((NS == 3 ? 60 : 36) + (GB ? (sizeof(AT) == 2 ? 16 : 4) : 0)) + STEPS - 1) / STEPS;
-            __builtin_amdgcn_sched_group_barrier(0x100, STEPS > 1 ? 2 * NS : NS, 0);
+            constexpr int VPS = (NSLOT * ((NS == 3 ? 60 : 36) + (GB ? (sizeof(AT) == 2 ? 16 : 4) : 0)) + (FDW ? (NS == 3 ? 56 : 32) : 0) + STEPS - 1) / STEPS;
+            __builtin_amdgcn_sched_group_barrier(0x100, (SX > 0 ? NS : 2 * NS) + (STEPS > 1 ? (SX > 1 ? NS : 2 * NS) : 0), 0);
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
-                if (st + 2 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
+                if (st + 2 < STEPS) { if (st + 2 < SX) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0); else __builtin_amdgcn_sched_group_barrier(0x100, 2 * NS, 0); }
+                if (FDW && (st == SX - 2 || st == SX + 4)) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NS, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, VPS, 0);
-                bool item = false;
+                bool item = false, xitem = false;
 #pragma unroll
-                for (int k = 0; k < NSLOT; ++k) item = item || (k * STEPS) / NSLOT == st;
+                for (int k = 0; k < NITEM; ++k) { const bool hit = (k * STEPS) / NITEM == st; item = item || (hit && k < NSLOT); xitem = xitem || (hit && k >= NSLOT); }
                 if (item) {
                     __builtin_amdgcn_sched_group_barrier(0x200, NS, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, GB ? 4 : 2, 0);
+                }
+                if (xitem) {
+                    __builtin_amdgcn_sched_group_barrier(0x200, NS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
                 }
             }
         }
@@ -1177,6 +1338,28 @@ __global__ __launch_bounds__(kBlock, CT == 32 ? 1 : (CT == 16 ? 2 : 3)) void con
                 if (ml < A.Mout) A.part[(size_t)blockIdx.x * (2 * A.Mout) + (size_t)stat * A.Mout + ml] = s;
             }
         }
+    }
+    if constexpr (FDW) {
+        // ---- the block's backward-weights slab: fixed-order 4-wave sum through LDS; D row = 4 (lane >> 4) + r is ci (rows
+        // 8-15 repeat 0-7), column = lane & 15 is (dx, co): pair 0 -> taps kx = 1 - dx, pair 1 -> kx = 2 (dx = 1 unused) ----
+        __syncthreads();                                       // every wave is done with the images
+        float* const r4 = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r4[((wave * 6 + a) * 4 + r) * 64 + lane] = dacc[a][r];
+        __syncthreads();
+        const int wsize = 9 * A.dw_Cin * 8;
+        float* const out = A.dw_part + (size_t)blockIdx.x * (wsize + 8);
+        for (int e = tid; e < 6 * 4 * 64; e += kBlock) {
+            const float sv = (r4[e] + r4[1536 + e]) + (r4[3072 + e] + r4[4608 + e]);
+            const int ln = e & 63, r = (e >> 6) & 3, a = e >> 8;
+            const int m = 4 * (ln >> 4) + r, n = ln & 15, ky = a >> 1, kb = a & 1, dxn = n >> 3, co = n & 7;
+            const int kx = kb == 0 ? 1 - dxn : 2;
+            if (m < 8 && !(kb == 1 && dxn == 1)) out[((ky * 3 + kx) * A.dw_Cin + A.dw_ci_off + m) * 8 + co] = sv;
+        }
+        __syncthreads();
+        block_reduce_store<8>(bsum, r4, out + wsize, A.dw_bias ? 8 : 0);      // bias gradient = sum of dz over the block's pixels
     }
 }
 

@@ -50,6 +50,11 @@ struct IgemmArgs {
     const void* gb_z; const float* gb_bn;        // backward-data on the bf16-pipe kernels, BN-backward transform on load: x0 is
                                                  // the masked gradient g' of the layer, gb_z its raw output z, gb_bn its BN
                                                  // record (Cin channels): the stager forms dz = ga g' + gb z + gd (common.hpp)
+    // conv_bt_k FDW (backward-data launch that also reduces the layer's backward-weights, kernels_bx.hpp): the conv INPUT
+    // slice this launch's gradient belongs to -- dw_x = that producer's raw output z (B,Ho,Wo,Mout), dw_ab its BN record
+    // (rows a, b) -- the layer's partial-slab base [grid][9 * dw_Cin * Cin + Cin], the layer's input-channel count, this
+    // slice's first input channel, and whether this launch also writes the bias-gradient column sums
+    const void* dw_x; const float* dw_ab; float* dw_part; int dw_Cin, dw_ci_off, dw_bias;
     unsigned* fin_counter;                       // statistics finalized in this launch (last block): arrival counter, or nullptr
     const float* fin_gamma; const float* fin_beta; float* fin_bn; float* fin_mm; float* fin_mv;   // EPI_FWD: BnFinArgs fields
     float* fin_dgamma; float* fin_dbeta;         // EPI_MASK: BnBwdFinArgs fields (fin_bn = producer's record, fin_gamma its gamma)

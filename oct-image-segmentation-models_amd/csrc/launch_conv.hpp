@@ -92,15 +92,15 @@ int launch_thin8(IgemmArgs a, const LaunchCtx& c, int* rows) {
 
 // ---- bf16-pipe implicit GEMM (kernels_bx.hpp): NS = 3 split products in fp32 mode, 1 in bf16 mode ----
 // GB: the input is a masked gradient g' whose BN-backward transform is applied while it is staged (backward-data only)
-template <int KH, int AMODE, int EPI, int TH, int MB, int NW>
+template <int KH, int AMODE, int EPI, int TH, int MB, int NW, int NIMG = 2>
 int launch_bx_nw(IgemmArgs a, const LaunchCtx& c, int* rows) {
     a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, TH);
     dim3 grid(a.tiles, cdiv(a.Mout, MB), c.B), block(64 * NW);
     const bool gb = a.gb_z != nullptr;
-    char nm[72]; snprintf(nm, sizeof nm, "conv_bx_k<%d,%d,%d,%d,%d,%d,%d,%s%s>", KH, AMODE, EPI, TH, MB, a.act_bf16 ? 1 : 3, NW, AT_NAME(a.act_bf16), gb ? ",gb" : "");
+    char nm[80]; snprintf(nm, sizeof nm, "conv_bx_k<%d,%d,%d,%d,%d,%d,%d,%s%s%s>", KH, AMODE, EPI, TH, MB, a.act_bf16 ? 1 : 3, NW, AT_NAME(a.act_bf16), gb ? ",gb" : "", NIMG == 1 ? ",1img" : "");
     ProfScope ps(c.s, nm, c.layer, c.flops, c.bytes);
     *rows = c.B * a.tiles;
-    if constexpr (AMODE == A_UPF && EPI == EPI_FWD) {
+    if constexpr (AMODE == A_UPF && EPI == EPI_FWD && NIMG == 2) {
         if (a.flags & F_DROP) {
             if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, true, NW, bf16_t><<<grid, block, 0, c.s>>>(a);
             else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, true, NW, float><<<grid, block, 0, c.s>>>(a);
@@ -108,18 +108,18 @@ int launch_bx_nw(IgemmArgs a, const LaunchCtx& c, int* rows) {
             return 0;
         }
     }
-    if (a.flags & F_DROP) return fail(-3, "conv_bx_k: dropout on the input is only built for the up-conv forward");
+    if (a.flags & F_DROP) return fail(-3, "conv_bx_k: dropout on the input is only built for the up-conv forward (double-buffered form)");
     if constexpr (EPI != EPI_FWD) {
         if (gb) {
-            if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, false, NW, bf16_t, true><<<grid, block, 0, c.s>>>(a);
-            else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, false, NW, float, true><<<grid, block, 0, c.s>>>(a);
+            if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, false, NW, bf16_t, true, NIMG><<<grid, block, 0, c.s>>>(a);
+            else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, false, NW, float, true, NIMG><<<grid, block, 0, c.s>>>(a);
             HIP_OK(hipGetLastError());
             return 0;
         }
     }
     if (gb) return fail(-3, "conv_bx_k: the BN-backward transform on load is only built for backward-data launches");
-    if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, false, NW, bf16_t><<<grid, block, 0, c.s>>>(a);
-    else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, false, NW, float><<<grid, block, 0, c.s>>>(a);
+    if (a.act_bf16) conv_bx_k<KH, AMODE, EPI, TH, MB, 1, false, NW, bf16_t, false, NIMG><<<grid, block, 0, c.s>>>(a);
+    else conv_bx_k<KH, AMODE, EPI, TH, MB, 3, false, NW, float, false, NIMG><<<grid, block, 0, c.s>>>(a);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -137,6 +137,11 @@ int launch_bx(const IgemmArgs& a, const LaunchCtx& c, int* rows) {
         if (a.Mout % 64 == 0) return launch_bx_geo<KH, AMODE, EPI, 4, 64>(a, c, rows);
         return launch_bx_geo<KH, AMODE, EPI, 4, 32>(a, c, rows);
     } else {
+        // bx_two_blocks: 4-row tiles, 4-wave blocks with ONE input image, two blocks per CU (see conv_bx_k NIMG)
+        if (c.o->bx_two_blocks && !(a.flags & F_DROP)) {
+            if (a.Mout % 64 == 0) return launch_bx_nw<KH, AMODE, EPI, 4, 64, 4, 1>(a, c, rows);
+            return launch_bx_nw<KH, AMODE, EPI, 8, 32, 4, 1>(a, c, rows);
+        }
         if (a.Mout % 64 == 0) {
             if (blocks(8, 64) >= c.o->bx_min_blocks) return launch_bx_geo<KH, AMODE, EPI, 8, 64>(a, c, rows);
             return launch_bx_geo<KH, AMODE, EPI, 4, 64>(a, c, rows);
@@ -150,17 +155,31 @@ int launch_bx(const IgemmArgs& a, const LaunchCtx& c, int* rows) {
 template <int KH, int AMODE, int EPI>
 int launch_bt(IgemmArgs a, const LaunchCtx& c, int* rows) {
     a.tiles_x = cdiv(a.Wo, 32); a.tiles = a.tiles_x * cdiv(a.Ho, 8); a.total_tiles = c.B * a.tiles;
-    const int per_cu = a.Cin == 32 ? 1 : (a.Cin == 16 ? 2 : 3);     // what the LDS images and registers of the instantiation allow
+    const bool fdw = a.dw_part != nullptr;                          // the launch also reduces the layer's backward-weights (FDW)
+    const int per_cu = fdw ? 2 : (a.Cin == 32 ? 1 : (a.Cin == 16 ? 2 : 3));     // what the LDS images and registers of the instantiation allow
     const int want = c.o->bt_blocks_per_cu;
     const int nblk = std::min(a.total_tiles, want > 0 ? 256 * std::min(want, per_cu) : 256 * per_cu);
     const int bf = a.act_bf16 ? 1 : 0;
     const bool m2 = a.bt_m2 && a.Mout == 8 && AMODE != A_DOWN2 && (a.Cin == 8 || a.Cin == 16);
     const bool gb = a.gb_z != nullptr;
-    char nm[72]; snprintf(nm, sizeof nm, "conv_bt_k<%d,%d,%d,%d,%d,%s%s%s>", KH, AMODE, EPI, a.Cin, bf ? 1 : 3, AT_NAME(bf), m2 ? ",2px" : "", gb ? ",gb" : "");
+    char nm[72]; snprintf(nm, sizeof nm, "conv_bt_k<%d,%d,%d,%d,%d,%s%s%s%s>", KH, AMODE, EPI, a.Cin, bf ? 1 : 3, AT_NAME(bf), m2 ? ",2px" : "", gb ? ",gb" : "", fdw ? ",dw" : "");
     ProfScope ps(c.s, nm, c.layer, c.flops, c.bytes);
     if (a.bt_m2 && !m2) return fail(-3, "conv_bt_k: weights were prepared in the two-pixel form for a launch that cannot use it");
     if (gb && EPI == EPI_FWD) return fail(-3, "conv_bt_k: the BN-backward transform on load is only built for backward-data launches");
     *rows = nblk;
+    if (fdw) {
+        if constexpr (KH == 3 && AMODE == A_NORMAL && EPI != EPI_FWD) {
+            if (!(gb && a.Cin == 8 && a.Mout == 8 && a.dw_x && a.dw_ab))
+                return fail(-3, "conv_bt_k: fused backward-weights needs 8 K channels, 8 output channels and the transform on load");
+            if (m2) { if (bf) conv_bt_k<KH, AMODE, EPI, 8, 1, bf16_t, true, true, true><<<nblk, kBlock, 0, c.s>>>(a);
+                      else conv_bt_k<KH, AMODE, EPI, 8, 3, float, true, true, true><<<nblk, kBlock, 0, c.s>>>(a); }
+            else { if (bf) conv_bt_k<KH, AMODE, EPI, 8, 1, bf16_t, false, true, true><<<nblk, kBlock, 0, c.s>>>(a);
+                   else conv_bt_k<KH, AMODE, EPI, 8, 3, float, false, true, true><<<nblk, kBlock, 0, c.s>>>(a); }
+            HIP_OK(hipGetLastError());
+            return 0;
+        }
+        return fail(-3, "conv_bt_k: fused backward-weights is only built for 3x3 backward-data launches");
+    }
 #define BT_LAUNCH(CT, M2V, GBV) do { if (bf) conv_bt_k<KH, AMODE, EPI, CT, 1, bf16_t, M2V, GBV><<<nblk, kBlock, 0, c.s>>>(a); \
                                      else conv_bt_k<KH, AMODE, EPI, CT, 3, float, M2V, GBV><<<nblk, kBlock, 0, c.s>>>(a); } while (0)
 #define BT_CASE(CT, M2V) case CT: if constexpr (EPI != EPI_FWD) { if (gb) { BT_LAUNCH(CT, M2V, true); break; } } BT_LAUNCH(CT, M2V, false); break;

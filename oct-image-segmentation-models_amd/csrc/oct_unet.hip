@@ -724,8 +724,18 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         l.g_masked = fuse;
         rc = bn_backward(h, li, pending_nblk, B, s, fuse, false);
         if (rc) return rc;
-        const bool fork = side_ok;     // (the per-launch profiler wants serial launches)
-        if (fork) {
+        // 3x3 layers with 8 output channels on the thin kernel (the full-resolution convs): their backward-data launches
+        // reduce the backward-weights too (conv_bt_k FDW) -- g', z and the producer's z are read once for both
+        bool fdw = false;
+        if (fuse && o.fuse_dw_thin && l.kh == 3 && l.cout == 8 && !l.drop_in && (l.src == SRC_PREV || l.src == SRC_CONCAT) &&
+            bx_bwd_cg(l) == 8 && l.dw_rows >= std::min(B * cdiv(l.W, 32) * cdiv(l.H, 8), 512) &&      // (one slab per block of that launch)
+            conv_route(dx_args(nullptr, 8, 0, nullptr, false), A_NORMAL, o) == ROUTE_BT &&
+            (l.src != SRC_CONCAT || conv_route(dx_args(nullptr, 8, 8, nullptr, false), A_NORMAL, o) == ROUTE_BT))
+            fdw = true;
+        const bool fork = side_ok && !fdw;     // (the per-launch profiler wants serial launches)
+        if (fdw) {
+            // nothing here: the slabs are written by the backward-data launches below
+        } else if (fork) {
             hipEvent_t e = h->fork_ev[1 + li % (h->fork_ev.size() - 1)];
             HIP_OK(hipEventRecord(e, s));                        // dz of block li is final here
             HIP_OK(hipStreamWaitEvent(h->side, e, 0));
@@ -747,13 +757,18 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         if (l.src == SRC_INPUT) break;
         if (prep_pending) { HIP_OK(hipStreamWaitEvent(s, h->prep_ev, 0)); prep_pending = false; }   // first backward-data launch
         int rows = 0;
-        auto dx = [&](void* gout, int Cg, int ci_off, const Layer* prod, bool up) -> int {
+        // (xsrc: with fdw, the layer whose output is this launch's slice of the conv input -- `prod` when the launch masks)
+        auto dx = [&](void* gout, int Cg, int ci_off, const Layer* prod, bool up, const Layer* xsrc = nullptr, bool first = true) -> int {
             IgemmArgs g = dx_args(gout, Cg, ci_off, prod, up);
             if (fuse) { g.gb_z = l.z; g.gb_bn = l.bn; }
             const double px = (double)B * l.H * l.W, pxg = (double)B * g.Ho * g.Wo;
-            const double fl = 2.0 * l.kh * l.kw * Cg * l.cout * px;          // algorithmic flops of the original conv's dX
+            double fl = 2.0 * l.kh * l.kw * Cg * l.cout * px;                // algorithmic flops of the original conv's dX
             const int es = h->cfg.dtype ? 2 : 4;
-            const double by = px * l.cout * es * (fuse ? 2 : 1) + pxg * Cg * es * (prod ? 2 : 1);
+            double by = px * l.cout * es * (fuse ? 2 : 1) + pxg * Cg * es * (prod ? 2 : 1);
+            if (fdw) {
+                g.dw_x = xsrc->z; g.dw_ab = xsrc->bn; g.dw_part = l.dwp; g.dw_Cin = l.cin; g.dw_ci_off = ci_off; g.dw_bias = first ? 1 : 0;
+                fl *= 2; if (!prod) by += pxg * Cg * es;                      // + the dW flops; + the X read where no mask reads it
+            }
             const LaunchCtx lc{&o, B, s, l.name, fl, by};
             if (up) return launch_igemm<3, A_DOWN2, EPI_MASK>(g, lc, &rows);
             return prod ? launch_igemm<3, A_NORMAL, EPI_MASK>(g, lc, &rows)
@@ -762,9 +777,10 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         switch (l.src) {
             case SRC_PREV: {
                 Layer& p = pl.L[li - 1];
-                rc = dx(p.g, p.cout, 0, &p, false);
+                rc = dx(p.g, p.cout, 0, &p, false, &p, true);
                 if (rc) return rc;
                 pending_nblk = rows;
+                if (fdw) queue_reduce(h, l, rows);
                 break;
             }
             case SRC_POOL: {  // gradient wrt the pooled tensor (raw), then route through the pool into block li-1
@@ -804,12 +820,17 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             case SRC_CONCAT: {
                 Layer& p = pl.L[li - 1]; Layer& k = pl.L[l.skip_from];
                 // skip half first (raw, merged later by pool_bwd of that encoder level) ...
-                rc = dx(k.g, k.cout, p.cout, nullptr, false);
+                rc = dx(k.g, k.cout, p.cout, nullptr, false, &k, false);
                 if (rc) return rc;
+                const int rows_skip = rows;
                 // ... then the up-path half, whose statistics must be the ones pending for block li-1
-                rc = dx(p.g, p.cout, 0, &p, false);
+                rc = dx(p.g, p.cout, 0, &p, false, &p, true);
                 if (rc) return rc;
                 pending_nblk = rows;
+                if (fdw) {
+                    if (rows != rows_skip) return fail(-3, "fused backward-weights: the two halves ran different grids");
+                    queue_reduce(h, l, rows);
+                }
                 break;
             }
             default: return fail(-3, "backward: bad src");
@@ -1165,7 +1186,8 @@ const Opt k_opts[] = {
     {"dwbt_f32_all", &Options::dwbt_f32_all, 0, 1}, {"bt_m2", &Options::bt_m2, 0, 1},
     {"fuse_first_apply", &Options::fuse_first_apply, 0, 1}, {"fuse_bn_apply", &Options::fuse_bn_apply, 0, 1},
     {"fuse_bn_finalize", &Options::fuse_bn_finalize, 0, 1}, {"bx_waves", &Options::bx_waves, 4, 8},
-    {"dw_side_stream", &Options::dw_side_stream, 0, 1}, {"timing_skip", &Options::timing_skip, 0, 255},
+    {"dw_side_stream", &Options::dw_side_stream, 0, 1}, {"timing_skip", &Options::timing_skip, 0, 255}, {"fuse_dw_thin", &Options::fuse_dw_thin, 0, 1},
+    {"bx_two_blocks", &Options::bx_two_blocks, 0, 1},
 };
 }  // namespace
 

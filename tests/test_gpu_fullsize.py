@@ -112,10 +112,16 @@ def test_bench_configuration_matches_the_fp64_oracle():
     """BASELINE configs[1] exactly as ``bench.py`` times it -- 256x512x1, pool_layers 4, 3 classes, batch 32, fp32,
     default options (so: the grid-size dependent kernel selection, persistent block counts and statistic-row counts of
     B = 32) -- against ``oracle/unet_torch.py`` in fp64 (reference: training/training.py:401-407).  Forward: every
-    layer's pre-BN output z and the loss.  Backward: every layer's dz from the head downwards and every gradient tensor.
-    An fp32 path can only differ from an fp64 one at ReLU kinks (|BN pre-activation| below fp32 rounding flips a mask
-    and the flip spreads over a few pixels per layer), so backward tensors are gated by quantiles: at least 99.9 % of the
-    elements within 5e-4 of the tensor's scale and a kernel-gradient relative L2 error of at most 1e-3."""
+    layer's pre-BN output z (1e-4 of its scale) and the loss (1e-5).  Backward: every layer's dz from the head downwards
+    and every gradient tensor.
+
+    An fp32 path can only differ from the fp64 one through rounding, but on a ReLU net rounding is amplified at kinks: an
+    element whose BN pre-activation is within fp32 rounding of zero flips its mask, is then wrong by its whole value, and
+    the flip spreads (3x3 per conv, and through the BN-backward means to every element) as the gradient travels down.
+    How much of that is inherent is MEASURED, not assumed: the same oracle run in fp32 (torch CPU, a different summation
+    order, same inputs) against its own fp64 run gives the yardstick; the HIP path must stay within 3x of it (plus a
+    floor), layer by layer -- quantile (share of elements beyond 5e-4 of the tensor's scale) and relative L2 -- and every
+    kernel gradient within max(1e-3, 3x yardstick) relative L2."""
     from oct_image_segmentation_models_amd.engine import UNetEngine
     from oracle import unet_torch as ot
     B, P = 32, 4
@@ -136,46 +142,67 @@ def test_bench_configuration_matches_the_fp64_oracle():
     eng.backward(l, macro=True, loss_scale=1.0)
     g = eng.grads.cpu().numpy().astype(np.float64)
     nb = len(eng.layers) - 1
+    names = [L_["name"] for L_ in eng.layers]
 
-    # ---- the oracle: one fp64 forward + autograd backward over the same 32 scans ----
-    tp, ts = ot.to_torch(params, state, dtype=torch.float64, requires_grad=True)
-    zs = []
-    probs = ot.forward(cfg, tp, ts, torch.tensor(on.preprocess_u8(img, np.float64)), training=True,
-                       dropout_mask=torch.tensor(mask), collect_z=zs)
-    y = torch.nn.functional.one_hot(torch.tensor(lab[..., 0].astype("int64")), C).double()
-    loss = ot.dice_loss(y, probs, macro=True)
-    loss.backward()
-    assert abs(float(loss4[0]) - float(loss)) < 1e-5, (float(loss4[0]), float(loss))
+    def oracle(dtype):
+        """(loss, [z per layer, NHWC], [dz per layer], [grad dict per layer]) of one forward + autograd backward"""
+        tp, ts = ot.to_torch(params, state, dtype=dtype, requires_grad=True)
+        zs = []
+        npdt = np.float64 if dtype == torch.float64 else np.float32
+        probs = ot.forward(cfg, tp, ts, torch.tensor(on.preprocess_u8(img, npdt)), training=True,
+                           dropout_mask=torch.tensor(mask.astype(npdt)), collect_z=zs)
+        y = torch.nn.functional.one_hot(torch.tensor(lab[..., 0].astype("int64")), C).to(dtype)
+        loss = ot.dice_loss(y, probs, macro=True)
+        loss.backward()
+        z = [t.detach().permute(0, 2, 3, 1).numpy() for t in zs]
+        dz = [t.grad.permute(0, 2, 3, 1).numpy().astype(np.float64) for t in zs]
+        gr = [{k: v.grad.numpy().astype(np.float64).ravel() for k, v in p.items()} for p in tp]
+        return float(loss.detach()), z, dz, gr
 
-    # forward, per layer
-    for li in range(nb):
-        zr = zs[li].detach().permute(0, 2, 3, 1).numpy()
-        z = eng.debug_activation(li, 0)[:B].cpu().numpy()
-        err = np.abs(z - zr).max() / np.abs(zr).max()
-        assert err < 1e-4, f"layer {li} {eng.layers[li]['name']}: z differs by {err:.2e} of its scale"
-    # backward, per layer from the head downwards
-    worst_q = 0.0
-    for li in range(nb - 1, -1, -1):
-        dzr = zs[li].grad.permute(0, 2, 3, 1).numpy()
-        dz = eng.debug_dz(li)[:B].cpu().numpy()
-        scale = np.abs(dzr).max()
-        bad = float((np.abs(dz - dzr) > 5e-4 * scale).mean())
-        worst_q = max(worst_q, bad)
-        assert bad <= 1e-3, f"layer {li} {eng.layers[li]['name']}: {bad:.2e} of dz beyond 5e-4 of its scale"
-        assert np.linalg.norm(dz - dzr) <= 2e-3 * np.linalg.norm(dzr), eng.layers[li]["name"]
-    # every gradient tensor
-    for L_, p_ in zip(eng.layers, tp):
-        n = L_["kh"] * L_["kw"] * L_["cin"] * L_["cout"]; c = L_["cout"]
-        gk, rk = g[L_["kernel_off"]:L_["kernel_off"] + n], p_["kernel"].grad.numpy().ravel()
-        assert np.linalg.norm(gk - rk) <= 1e-3 * np.linalg.norm(rk), f"{L_['name']}.kernel"
-        kscale = np.abs(rk).max()
-        pieces = [("bias", L_["bias_off"])] + ([("gamma", L_["gamma_off"]), ("beta", L_["beta_off"])] if L_["has_bn"] else [])
-        for key, off in pieces:
-            rv = p_[key].grad.numpy().ravel()
-            # a conv bias ahead of a BN has an analytically zero gradient: judge it on the kernel's scale
+    loss64, z64, dz64, g64 = oracle(torch.float64)
+    assert abs(float(loss4[0]) - loss64) < 1e-5, (float(loss4[0]), loss64)
+    for li in range(nb):                                    # forward, per layer
+        zh = eng.debug_activation(li, 0)[:B].cpu().numpy()
+        err = np.abs(zh - z64[li]).max() / np.abs(z64[li]).max()
+        assert err < 1e-4, f"layer {li} {names[li]}: z differs by {err:.2e} of its scale"
+    del z64
+    loss32, _, dz32, g32 = oracle(torch.float32)            # the yardstick: fp32 torch vs fp64 torch
+
+    def dev(a, ref):
+        scale = np.abs(ref).max()
+        return float((np.abs(a - ref) > 5e-4 * scale).mean()), float(np.linalg.norm(a - ref) / np.linalg.norm(ref))
+
+    rows = []
+    for li in range(nb - 1, -1, -1):                        # backward, per layer from the head downwards
+        qh, lh = dev(eng.debug_dz(li)[:B].cpu().numpy(), dz64[li])
+        qy, ly = dev(dz32[li], dz64[li])
+        rows.append((names[li], qh, qy, lh, ly))
+    print("dz vs the fp64 oracle: layer, share of elements beyond 5e-4 of scale (HIP | fp32 torch), relative L2 (HIP | fp32 torch)")
+    for r in rows:
+        print(f"   {r[0]:12s} {r[1]:9.2e} {r[2]:9.2e}   {r[3]:9.2e} {r[4]:9.2e}")
+    krows = []
+    for li, L_ in enumerate(eng.layers):
+        n = L_["kh"] * L_["kw"] * L_["cin"] * L_["cout"]
+        gk = g[L_["kernel_off"]:L_["kernel_off"] + n]
+        krows.append((L_["name"], float(np.linalg.norm(gk - g64[li]["kernel"]) / np.linalg.norm(g64[li]["kernel"])),
+                      float(np.linalg.norm(g32[li]["kernel"] - g64[li]["kernel"]) / np.linalg.norm(g64[li]["kernel"]))))
+    print("kernel gradients, relative L2 vs fp64 (HIP | fp32 torch):")
+    for r in krows:
+        print(f"   {r[0]:12s} {r[1]:9.2e} {r[2]:9.2e}")
+    for name, qh, qy, lh, ly in rows:
+        assert qh <= 3 * qy + 1e-4, f"{name}: {qh:.2e} of dz beyond 5e-4 of its scale (fp32 yardstick {qy:.2e})"
+        assert lh <= 3 * ly + 1e-3, f"{name}: dz relative L2 {lh:.2e} (fp32 yardstick {ly:.2e})"
+    for name, eh, ey in krows:
+        assert eh <= max(1e-3, 3 * ey), f"{name}.kernel: relative L2 {eh:.2e} (fp32 yardstick {ey:.2e})"
+    for li, L_ in enumerate(eng.layers):                    # bias / gamma / beta on the layer's kernel-gradient scale
+        c = L_["cout"]
+        kscale = np.abs(g64[li]["kernel"]).max()
+        for key, off in [("bias", L_["bias_off"])] + ([("gamma", L_["gamma_off"]), ("beta", L_["beta_off"])] if L_["has_bn"] else []):
+            rv = g64[li][key]
             scale = max(np.abs(rv).max(), kscale if key == "bias" else 0.0, 1e-12)
-            assert np.abs(g[off:off + c] - rv).max() <= 1e-3 * scale, f"{L_['name']}.{key}"
-    print(f"B=32 oracle parity: loss {float(loss4[0]):.6f} vs {float(loss):.6f}; worst dz outlier fraction {worst_q:.2e}")
+            eh = np.abs(g[off:off + c] - rv).max() / scale
+            ey = np.abs(g32[li][key] - rv).max() / scale
+            assert eh <= max(1e-3, 3 * ey), f"{L_['name']}.{key}: {eh:.2e} of scale (fp32 yardstick {ey:.2e})"
 
 
 def _bf16_round(a):

@@ -58,7 +58,7 @@ DROP_STEP = 3
 
 @pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111", "dw16_padded",
                         "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all", "bt_one_px", "bn_apply_separate",
-                        "bn_finalize_separate"])
+                        "bn_finalize_separate", "bx_two_blocks", "dw_thin_separate"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant: for the thin layers the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels (otherwise only chosen on large grids); for the wide layers the
@@ -68,12 +68,14 @@ def variant(request):
     v = request.param
     _hip.set_option("bx_min_blocks", 1 if v.startswith("bx_tall") else 256)
     _hip.set_option("bx_waves", 4 if v == "bx_tall_w4" else 8)
+    _hip.set_option("bx_two_blocks", 1 if v == "bx_two_blocks" else 0)   # wide launches as one-image 4-wave blocks, two per CU
     _hip.set_option("mfma_mode", 0 if v == "f32_pipe" else 1)
     _hip.set_option("dwbt_f32_all", 1 if v == "dwbt_all" else 0)     # fp32 mode: every thin dW shape on the bf16 pipe
     _hip.set_option("bt_m2", 0 if v == "bt_one_px" else 1)           # thin kernel: 8-channel launches without the two-pixel form
     _hip.set_option("fuse_first_apply", 0 if v == "bn_apply_separate" else 1)   # bn_bwd_apply as its own pass: block 0 ...
     _hip.set_option("fuse_bn_apply", 0 if v == "bn_apply_separate" else 1)      # ... and every other block
     _hip.set_option("fuse_bn_finalize", 0 if v == "bn_finalize_separate" else 1)   # bn_*_finalize as their own launches
+    _hip.set_option("fuse_dw_thin", 0 if v == "dw_thin_separate" else 1)   # 8-channel 3x3 layers: backward-weights as their own kernel
     _hip.set_option("igemm_persistent_min_tiles", 1 if v == "persistent" else 1 << 30)
     _hip.set_option("thin8_min_tiles", 1 if v == "thin8_valu" or v.startswith("pair8") else 1 << 30)
     _hip.set_option("pair8_min_tiles", 1 if v.startswith("pair8") else 1 << 30)
@@ -82,12 +84,14 @@ def variant(request):
     yield v
     _hip.set_option("bx_min_blocks", 256)
     _hip.set_option("bx_waves", 8)
+    _hip.set_option("bx_two_blocks", 0)
     _hip.set_option("mfma_mode", 1)
     _hip.set_option("dwbt_f32_all", 0)
     _hip.set_option("bt_m2", 1)
     _hip.set_option("fuse_first_apply", 1)
     _hip.set_option("fuse_bn_apply", 1)
     _hip.set_option("fuse_bn_finalize", 1)
+    _hip.set_option("fuse_dw_thin", 1)
     _hip.set_option("dwpair8_enable", 1)
     _hip.set_option("igemm_persistent_min_tiles", 2048)
     _hip.set_option("thin8_min_tiles", 2048)
@@ -477,6 +481,7 @@ def test_bn_backward_on_load_equals_the_separate_pass(dtype, geo):
     x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
     got, applied = {}, {}
     try:
+        _hip.set_option("fuse_dw_thin", 0)       # (same backward-weights kernels on both routes: this test is about dz)
         for fuse in (1, 0):
             _hip.set_option("fuse_first_apply", fuse); _hip.set_option("fuse_bn_apply", fuse)
             eng = UNetEngine(device="cuda:0", input_channels=1, num_classes=C, image_height=H, image_width=W,
@@ -499,9 +504,53 @@ def test_bn_backward_on_load_equals_the_separate_pass(dtype, geo):
                 assert eng.debug_activation(0, 1)[:B].float().abs().sum().item() > 0
             got[fuse] = eng.grads.clone()
     finally:
-        _hip.set_option("fuse_first_apply", 1); _hip.set_option("fuse_bn_apply", 1)
+        _hip.set_option("fuse_first_apply", 1); _hip.set_option("fuse_bn_apply", 1); _hip.set_option("fuse_dw_thin", 1)
     assert torch.isfinite(got[1]).all() and got[1].abs().max() > 0
     assert torch.equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_backward_weights_inside_the_backward_data_launch(dtype):
+    """3x3 layers with 8 output channels (the full-resolution convs): by default their backward-data launches also reduce
+    the layer's backward-weights (conv_bt_k FDW) -- no separate dW kernel, g', z and the producer's z read once.  Same
+    products, another summation order: every gradient equals the separate-kernel route to fp32 accumulation accuracy (and
+    both are checked against the oracle by the variant tests), the dW kernels of those layers are really gone, and
+    everything else (backward-data results, BN statistics) is bit-identical."""
+    from oct_image_segmentation_models_amd import _hip
+    from oct_image_segmentation_models_amd.engine import UNetEngine
+    B, H, W, C = 3, 40, 96, 3                        # ragged against the 8 x 32 tile
+    images, labels = data(B, H, W, C, 1, seed=23)
+    x = torch.from_numpy(images).cuda(); lab = torch.from_numpy(labels[..., 0].copy()).cuda()
+    got, gbuf = {}, {}
+    try:
+        for fdw in (1, 0):
+            _hip.set_option("fuse_dw_thin", fdw)
+            eng = UNetEngine(device="cuda:0", input_channels=1, num_classes=C, image_height=H, image_width=W,
+                             start_neurons=8, pool_layers=2, max_batch=B, training=True, seed=9, init_seed=4,
+                             dtype="bfloat16" if dtype == "bf16" else "float32")
+            eng.set_dropout_step(2)
+            eng.profile_begin()
+            eng.forward(x, training=True, labels=lab, want_probs=False); eng.loss_dice(); eng.backward(lab, macro=True)
+            ents = eng.profile_end()
+            fused = {e["layer"] for e in ents if e["kernel"].startswith("conv_bt_k") and e["kernel"].endswith(",dw>")}
+            dwk = {e["layer"] for e in ents if e["kernel"].startswith("conv_dw") and not e["kernel"].startswith("conv_dw_first")}
+            thin3 = {L["name"] for L in eng.layers if L["kh"] == 3 and L["cout"] == 8 and L["cin"] in (8, 16)}
+            assert thin3 == {"enc0.conv1", "dec1.conv0", "dec1.conv1"}
+            assert fused == (thin3 if fdw else set()) and not (fused & dwk) and (thin3 <= dwk or fdw), (fused, dwk)
+            got[fdw] = eng.grads.clone()
+            gbuf[fdw] = [eng.debug_activation(li, 1)[:B].clone() for li in range(len(eng.layers) - 1)]
+    finally:
+        _hip.set_option("fuse_dw_thin", 1)
+    for a, b in zip(gbuf[1], gbuf[0]):               # masked gradients of every block: the dX results did not move
+        assert torch.equal(a, b)
+    g1, g0 = got[1].cpu().numpy().astype(np.float64), got[0].cpu().numpy().astype(np.float64)
+    tol = 2e-2 if dtype == "bf16" else 1e-5          # (bf16 mode: the two routes round X / dz to bf16 identically, sums differ)
+    for L in eng.layers:
+        n = L["kh"] * L["kw"] * L["cin"] * L["cout"]
+        a, b = g1[L["kernel_off"]:L["kernel_off"] + n], g0[L["kernel_off"]:L["kernel_off"] + n]
+        assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-30), L["name"]
+        a, b = g1[L["bias_off"]:L["bias_off"] + L["cout"]], g0[L["bias_off"]:L["bias_off"] + L["cout"]]
+        assert np.abs(a - b).max() <= tol * max(np.abs(g0[L["kernel_off"]:L["kernel_off"] + n]).max(), 1e-30), L["name"]
 
 
 @pytest.mark.parametrize("clip_mod", [0, 1])

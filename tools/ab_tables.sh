@@ -7,7 +7,7 @@ mkdir -p $ROOT/gpurun_out
 i=0
 for O in "$@"; do
   if [ "$O" = "default" ]; then unset OCT_OPTIONS; else export OCT_OPTIONS="$O"; fi
-  timeout -k 10 200 python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-inference --dump-profile $ROOT/gpurun_out/${TAG}_table$i.json > $ROOT/gpurun_out/${TAG}_$i.json 2> $ROOT/gpurun_out/${TAG}_$i.err || { tail -5 $ROOT/gpurun_out/${TAG}_$i.err; }
+  timeout -k 10 200 python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-inference --no-collective-leg --dump-profile $ROOT/gpurun_out/${TAG}_table$i.json > $ROOT/gpurun_out/${TAG}_$i.json 2> $ROOT/gpurun_out/${TAG}_$i.err || { tail -5 $ROOT/gpurun_out/${TAG}_$i.err; }
   python3 -c "
 import json
 d = json.loads(open('$ROOT/gpurun_out/${TAG}_$i.json').read().strip().splitlines()[-1])

@@ -5,6 +5,6 @@ set -uo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for O in "default" "$@"; do
   if [ "$O" = "default" ]; then unset OCT_OPTIONS; else export OCT_OPTIONS="$O"; fi
-  R=$(timeout -k 10 120 python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile --no-inference 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['step_ms_median_events'])") || R="failed"
+  R=$(timeout -k 10 120 python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile --no-inference --no-collective-leg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['step_ms_median_events'])") || R="failed"
   echo "$O : $R"
 done
