@@ -176,6 +176,11 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   "focal_clip_modulation" (default 0): see oct_unet_set_focal_dice.
  * The rest are tuning knobs (results do not depend on them beyond fp32 rounding, only which kernel variant runs):
  *   "bx_min_blocks" (256): a wide bf16-pipe launch takes the taller pixel tile only if that still yields this many blocks.
+ *   "bx_two_blocks" (1): wide bf16-pipe launches (3x3 and 2x2-over-upsample) run as 4-wave blocks with ONE input image in LDS,
+ *   two blocks per CU -- each block's prologue, barriers and epilogue hide behind the other's MFMAs; 0 = the 8-wave blocks
+ *   with a double-buffered image, one per CU (then "bx_min_blocks" / "bx_waves" pick their tile height and wave count).
+ *   "fuse_dw_thin" (1): 3x3 layers with 8 output channels (the full-resolution convs): the backward-data launches also
+ *   reduce the layer's backward-weights (conv_bt_k FDW); 0 = a separate backward-weights kernel.
  *   "bx_waves" (8 | 4): waves per block of conv_bx_k where the tile has >= 8 rows (two / one per SIMD).
  *   "dwbx_blocks" (256): grid target of the wide bf16-pipe backward-weights kernel.
  *   "bt_blocks_per_cu" (0 = as many as the LDS images allow): persistent blocks of the thin bf16-pipe kernel.

@@ -27,7 +27,8 @@ struct Options {
     int pair_geo = 221;             // pixel-pair kernel geometry NWY*100 + NWX*10 + RPW
     int pair_min_tiles = 2048;      // pixel tiles from which 3x3 layers with 8 output channels use the pixel-pair MFMA kernel
     int dw_side_stream = 1;         // backward-weights kernels on the handle's side stream beside the backward-data chain
-    int bx_two_blocks = 0;          // wide bf16-pipe launches as 4-wave blocks with one input image, two per CU (experiment)
+    int bx_two_blocks = 1;          // wide bf16-pipe launches (3x3, 2x2-over-upsample) as 4-wave blocks with ONE input image, two per CU
+                                    // (cfg-A +1.4 %, cfg-C bf16 +5.3 % over the 8-wave double-buffered blocks, which 0 selects)
     int bx_waves = 8;               // waves per block of conv_bx_k where the tile has >= 8 rows
     int fuse_first_apply = 1;       // the first conv's BN-backward transform is applied inside its backward-weights kernel
     int fuse_bn_apply = 1;          // every other block: the transform is applied by the dX / dW kernels while they stage g'
@@ -37,6 +38,7 @@ struct Options {
     int bt_m2 = 1;                  // conv_bt_k: 8-output-channel launches in the two-pixel form
     int dwbt_f32_all = 0;           // 1: fp32 mode also takes conv_dwbt_k for every thin shape
     int bt_blocks_per_cu = 0;       // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows)
+    int dwbx_enable = 1;            // wide backward-weights on the bf16 pipe (0: the fp32-pipe conv_dw32_k; experiments)
     int dwbx_blocks = 256;          // target grid of a bf16-pipe backward-weights launch
     int bx_min_blocks = 256;        // a bf16-pipe launch takes the taller pixel tile only if that still yields this many blocks
     int mfma_mode = 1;              // 1: bf16 MFMA pipe (split products in fp32 mode); 0: the fp32-pipe kernels everywhere

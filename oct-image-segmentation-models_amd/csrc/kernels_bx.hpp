@@ -229,20 +229,7 @@ __global__ __launch_bounds__(64 * NW, NIMG == 1 ? (NW == 4 ? 2 : 1) : 1) void co
     // affine rows of the (possibly concatenated) input, once per block: (a, b) of y = max(a*z + b, lo); identity without BN
     const bool aff = (A.flags & F_AFF) != 0;
     const float lo = aff ? 0.f : -3.0e38f;
-    for (int c = tid; c < nch * 16; c += NTHR) {
-        float av = 1.f, bv = 0.f;
-        if (aff && c < A.Cin) {
-            const bool two = (A.flags & F_TWO) && c >= A.C0;
-            const float* ab = two ? A.ab1 : A.ab0; const int C = two ? A.C1 : A.C0, cc = two ? c - A.C0 : c;
-            av = ab[cc]; bv = ab[C + cc];
-        }
-        if constexpr (GB) {
-            const bool ok = c < A.Cin;
-            av = ok ? A.gb_bn[BN_GA * A.Cin + c] : 0.f; bv = ok ? A.gb_bn[BN_GD * A.Cin + c] : 0.f;
-            ABs[2 * MAXC + c] = ok ? A.gb_bn[BN_GB * A.Cin + c] : 0.f;
-        }
-        ABs[c] = av; ABs[MAXC + c] = bv;
-    }
+    // (the rows themselves are fetched in the pipeline prologue, BEHIND the first tile's loads: one latency, not two)
     typename Raw4<AT>::type pin[NSLOT][2], pz[GB ? NSLOT : 1][2];
     auto load_in = [&](int c0) {
         const int c = c0 + 8 * hh;
@@ -404,17 +391,69 @@ __global__ __launch_bounds__(64 * NW, NIMG == 1 ? (NW == 4 ? 2 : 1) : 1) void co
     // ---- pipeline over (chunk, tap row) ----
     dma_slab(0, 0, 0);
     load_in(0);
+    for (int c = tid; c < nch * 16; c += NTHR) {
+        float av = 1.f, bv = 0.f;
+        if (aff && c < A.Cin) {
+            const bool two = (A.flags & F_TWO) && c >= A.C0;
+            const float* ab = two ? A.ab1 : A.ab0; const int C = two ? A.C1 : A.C0, cc = two ? c - A.C0 : c;
+            av = ab[cc]; bv = ab[C + cc];
+        }
+        if constexpr (GB) {
+            const bool ok = c < A.Cin;
+            av = ok ? A.gb_bn[BN_GA * A.Cin + c] : 0.f; bv = ok ? A.gb_bn[BN_GD * A.Cin + c] : 0.f;
+            ABs[2 * MAXC + c] = ok ? A.gb_bn[BN_GB * A.Cin + c] : 0.f;
+        }
+        ABs[c] = av; ABs[MAXC + c] = bv;
+    }
     __syncthreads();                 // ABs visible
     begin_store(0);
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) store_slot(k, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                 // image 0 + slab (0,0) landed
+    // EPI_MASK: the producer's z at this wave's output pixels (mask + BN-backward sums of the epilogue) is requested
+    // before the LAST tap row of the last K chunk -- the input prefetch registers are dead by then -- instead of behind it
+    typename Raw4<AT>::type zraw[EPI == EPI_MASK ? NTW : 1][EPI == EPI_MASK ? MTW : 1][EPI == EPI_MASK ? QUADS : 1];
+    auto load_zraw = [&]() {
+        if constexpr (EPI == EPI_MASK) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int y = y0 + wave * NTW + nt, x = x0 + j;
+                const bool pvalid = y < A.Ho && x < A.Wo;
+                const size_t pix = pvalid ? ((size_t)b * A.Ho + y) * A.Wo + x : 0;
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int q = 0; q < QUADS; ++q) {
+                        const int m = m0 + mt * MT + 8 * q + 4 * h;
+                        zraw[nt][mt][q] = (pvalid && m < A.Mout) ? ldraw4<AT>(reinterpret_cast<const AT*>(A.zin) + pix * A.Mout + m) : raw_zero4<AT>();
+                    }
+            }
+        }
+    };
+    // ... and so are the epilogue's per-channel constants (bias, or the producer's BN rows): one value per thread, kept in a
+    // register until the weight slots they will be staged in are free
+    constexpr int EPN = EPI == EPI_MASK ? 4 * MB : (EPI == EPI_FWD ? MB : 0), EPF = (EPN + NTHR - 1) / NTHR;
+    float epi_pf[EPF > 0 ? EPF : 1];
+    auto load_epi = [&]() {
+#pragma unroll
+        for (int i = 0; i < EPF; ++i) {
+            const int e = tid + i * NTHR;
+            float v = 0.f;
+            if constexpr (EPI == EPI_FWD) { if (e < MB && m0 + e < A.Mout) v = A.bias[A.m_off + m0 + e]; }
+            else if constexpr (EPI == EPI_MASK) { if (e < 4 * MB && m0 + e % MB < A.Mout) v = A.bnin[(e / MB) * A.Mout + m0 + e % MB]; }
+            epi_pf[i] = v;
+        }
+    };
     int g = 0;
     for (int c = 0; c < nch; ++c) {
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky, ++g) {
             const bool last_row = ky == KH - 1, more = c + 1 < nch;
+            if (last_row && !more) {
+                if constexpr (NW == 4) load_zraw();      // (8-wave blocks live under the 256-register cap: there the 8 extra
+                load_epi();                              //  float4 spill 100 registers -- their z is requested after the loop)
+            }
             if (last_row && more) {
                 // The conversion below consumes the input registers requested two tap rows ago.  hipcc waits vmcnt(0)
                 // at their first use -- which would also wait for the weight DMA issued in THIS step (a full L2 round
@@ -458,29 +497,10 @@ __global__ __launch_bounds__(64 * NW, NIMG == 1 ? (NW == 4 ? 2 : 1) : 1) void co
     // ---- epilogue (same forms as conv_igemm_k; the weight slots are free now) ----
     float* const epi = reinterpret_cast<float*>(WTs);
     float* const red = reinterpret_cast<float*>(WTs + EPI_B);
-    if constexpr (EPI == EPI_FWD) {
-        for (int e = tid; e < MB; e += NTHR) epi[e] = m0 + e < A.Mout ? A.bias[A.m_off + m0 + e] : 0.f;
-    } else if constexpr (EPI == EPI_MASK) {
-        for (int e = tid; e < 4 * MB; e += NTHR) {
-            const int arr = e / MB, m = m0 + e % MB;
-            epi[e] = m < A.Mout ? A.bnin[arr * A.Mout + m] : 0.f;
-        }
-    }
-    typename Raw4<AT>::type zraw[EPI == EPI_MASK ? NTW : 1][EPI == EPI_MASK ? MTW : 1][EPI == EPI_MASK ? QUADS : 1];
-    if constexpr (EPI == EPI_MASK) {
+    if constexpr (NW != 4) load_zraw();
+    if constexpr (EPI != EPI_RAW) {
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int y = y0 + wave * NTW + nt, x = x0 + j;
-            const bool pvalid = y < A.Ho && x < A.Wo;
-            const size_t pix = pvalid ? ((size_t)b * A.Ho + y) * A.Wo + x : 0;
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                for (int q = 0; q < QUADS; ++q) {
-                    const int m = m0 + mt * MT + 8 * q + 4 * h;
-                    zraw[nt][mt][q] = (pvalid && m < A.Mout) ? ldraw4<AT>(reinterpret_cast<const AT*>(A.zin) + pix * A.Mout + m) : raw_zero4<AT>();
-                }
-        }
+        for (int i = 0; i < EPF; ++i) { const int e = tid + i * NTHR; if (e < EPN) epi[e] = epi_pf[i]; }     // (requested before the last tap row)
     }
     __syncthreads();
     float s1[MTW][ACC], s2[MTW][ACC];

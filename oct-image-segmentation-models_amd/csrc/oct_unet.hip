@@ -177,7 +177,7 @@ inline bool dwbt_ok(const Layer& l) {
 // dW plan: which kernel handles a layer, its channel chunking, pixel-tile height and pixel-block count
 DwPlan dw_plan(const Layer& l, int B, int mfma_mode, int bf16, const Options& o) {
     DwPlan p{};
-    if (mfma_mode && l.src != SRC_INPUT && l.kh != 1 && l.cin % 32 == 0 && l.cout % 32 == 0) {
+    if (mfma_mode && o.dwbx_enable && l.src != SRC_INPUT && l.kh != 1 && l.cin % 32 == 0 && l.cout % 32 == 0) {
         // wide layers on the bf16 pipe: one block per (32 ci, 32 co) pair and pixel slice, ~1 block per CU in total
         p.kind = 33; p.cic = 32; p.coc = 32; p.th = 4;
         p.chunks = (l.cin / 32) * (l.cout / 32);
@@ -1187,6 +1187,7 @@ const Opt k_opts[] = {
     {"fuse_first_apply", &Options::fuse_first_apply, 0, 1}, {"fuse_bn_apply", &Options::fuse_bn_apply, 0, 1},
     {"fuse_bn_finalize", &Options::fuse_bn_finalize, 0, 1}, {"bx_waves", &Options::bx_waves, 4, 8},
     {"dw_side_stream", &Options::dw_side_stream, 0, 1}, {"timing_skip", &Options::timing_skip, 0, 255}, {"fuse_dw_thin", &Options::fuse_dw_thin, 0, 1},
+    {"dwbx_enable", &Options::dwbx_enable, 0, 1},
     {"bx_two_blocks", &Options::bx_two_blocks, 0, 1},
 };
 }  // namespace

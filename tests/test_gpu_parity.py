@@ -58,7 +58,7 @@ DROP_STEP = 3
 
 @pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111", "dw16_padded",
                         "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all", "bt_one_px", "bn_apply_separate",
-                        "bn_finalize_separate", "bx_two_blocks", "dw_thin_separate"])
+                        "bn_finalize_separate", "bx_one_block", "dw_thin_separate"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant: for the thin layers the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels (otherwise only chosen on large grids); for the wide layers the
@@ -68,7 +68,8 @@ def variant(request):
     v = request.param
     _hip.set_option("bx_min_blocks", 1 if v.startswith("bx_tall") else 256)
     _hip.set_option("bx_waves", 4 if v == "bx_tall_w4" else 8)
-    _hip.set_option("bx_two_blocks", 1 if v == "bx_two_blocks" else 0)   # wide launches as one-image 4-wave blocks, two per CU
+    # wide launches: one-image 4-wave blocks, two per CU (default) / the 8-wave double-buffered blocks, also in their tall-tile forms
+    _hip.set_option("bx_two_blocks", 0 if v in ("bx_one_block", "bx_tall", "bx_tall_w4") else 1)
     _hip.set_option("mfma_mode", 0 if v == "f32_pipe" else 1)
     _hip.set_option("dwbt_f32_all", 1 if v == "dwbt_all" else 0)     # fp32 mode: every thin dW shape on the bf16 pipe
     _hip.set_option("bt_m2", 0 if v == "bt_one_px" else 1)           # thin kernel: 8-channel launches without the two-pixel form
@@ -84,7 +85,7 @@ def variant(request):
     yield v
     _hip.set_option("bx_min_blocks", 256)
     _hip.set_option("bx_waves", 8)
-    _hip.set_option("bx_two_blocks", 0)
+    _hip.set_option("bx_two_blocks", 1)
     _hip.set_option("mfma_mode", 1)
     _hip.set_option("dwbt_f32_all", 0)
     _hip.set_option("bt_m2", 1)
