@@ -230,6 +230,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # (the rehearsal flag travels to the ranks in the environment)
         sys.exit(spawn_ranks(args.gpus))
+    # stdout carries exactly ONE line, the JSON record: native libraries write banners straight to file descriptor 1 (RCCL
+    # prints its version block when a communicator is created), so fd 1 points at stderr for the whole run and the record
+    # goes to a private duplicate of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -490,7 +496,7 @@ def main():
     if rank == 0:
         if rehearsal:
             out["data"] = "synthetic (REHEARSAL: ranks share one GPU, gloo collective -- not a measurement)"
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n"); real_stdout.flush()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -1206,7 +1206,10 @@ __global__ __launch_bounds__(kBlock, FDW ? 2 : (CT == 32 ? 1 : (CT == 16 ? 2 : 3
             // FDW appends the backward-weights steps to the same sequence -- (X row r of this wave, kernel row ky, column
             // pair kb): A = the X row's fragments, B = dz at that tap pair, both through transposing reads -- so that their
             // LDS round trips hide behind the backward-data MFMAs and vice versa.
-            constexpr int SX = NTW * NG, SD = FDW ? 12 : 0, STEPS = SX + SD, DEPTH = 3;
+            // (look-ahead of the fragment ring: 2 steps; 1 where the 16-channel mask epilogue with the transform on load would
+            //  otherwise spill 20 registers under its 256-register budget)
+            constexpr int LA = (GB && CT == 16 && !M2 && EPI == EPI_MASK && NS == 3) ? 1 : 2;
+            constexpr int SX = NTW * NG, SD = FDW ? 12 : 0, STEPS = SX + SD, DEPTH = LA + 1;
             constexpr int NITEM = NSLOT + (FDW ? 1 : 0);          // staging items: the dz slots, then the X pixel
             bf16x8 bv[DEPTH][NS], af[FDW ? 2 : 1][NS];
             const char* const Xb = Xs + buf * XIMG_B + xlane;
@@ -1237,11 +1240,11 @@ __global__ __launch_bounds__(kBlock, FDW ? 2 : (CT == 32 ? 1 : (CT == 16 ? 2 : 3
                 }
             };
             fetch(0, bv[0]);
-            if (STEPS > 1) fetch(1, bv[1]);
+            if (LA > 1 && STEPS > 1) fetch(1, bv[1]);
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
-                if (st + 2 < STEPS) fetch(st + 2, bv[(st + 2) % DEPTH]);
+                if (st + LA < STEPS) fetch(st + LA, bv[(st + LA) % DEPTH]);
                 if constexpr (FDW) {
                     if (st == SX - 2) fetch_a(0, af[0]);           // two steps ahead of their first use
                     if (st == SX + 4) fetch_a(1, af[1]);
@@ -1284,10 +1287,10 @@ __global__ __launch_bounds__(kBlock, FDW ? 2 : (CT == 32 ? 1 : (CT == 16 ? 2 : 3
             // of the conversion VALU in their shadow, and behind an item its LDS writes and the loads that refill it
             constexpr int NPROD = NS == 3 ? 6 : 1;
             constexpr int VPS = (NSLOT * ((NS == 3 ? 60 : 36) + (GB ? (sizeof(AT) == 2 ? 16 : 4) : 0)) + (FDW ? (NS == 3 ? 56 : 32) : 0) + STEPS - 1) / STEPS;
-            __builtin_amdgcn_sched_group_barrier(0x100, (SX > 0 ? NS : 2 * NS) + (STEPS > 1 ? (SX > 1 ? NS : 2 * NS) : 0), 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, (SX > 0 ? NS : 2 * NS) + ((LA > 1 && STEPS > 1) ? (SX > 1 ? NS : 2 * NS) : 0), 0);
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
-                if (st + 2 < STEPS) { if (st + 2 < SX) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0); else __builtin_amdgcn_sched_group_barrier(0x100, 2 * NS, 0); }
+                if (st + LA < STEPS) { if (st + LA < SX) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0); else __builtin_amdgcn_sched_group_barrier(0x100, 2 * NS, 0); }
                 if (FDW && (st == SX - 2 || st == SX + 4)) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NS, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, VPS, 0);

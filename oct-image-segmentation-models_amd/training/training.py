@@ -155,7 +155,7 @@ def train_model(training_params: TrainingParams, mlflow_params=None):
         save_training_params_file(save_foldername, "\n".join(model_summary), model_container.get_config(),
                                   training_dataset_md5, c_weight, timestamp, training_params, optimizer)
 
-    # every rank draws the SAME global batches (its slice of each is taken in Model._device_batch): an unseeded
+    # every rank draws the SAME global batches (its slice of each is taken in Model._host_batch): an unseeded
     # run gets one OS-entropy seed from rank 0, not one per rank
     seed = parallel.shared_seed(training_params.seed) if parallel.world_size() > 1 else training_params.seed
     train_gen = data_gen.DataGenerator(train_images, train_labels, batch_size, training_params.aug_fn_args, training_params.aug_mode,

@@ -84,7 +84,7 @@ def _seed_worker(rank, world, port, tmpdir):
     taken = []
     for epoch in range(2):
         for _ in range(len(g)):
-            X, lab = g.next_batch_u8()             # the GLOBAL batch, as Model._device_batch sees it
+            X, lab = g.next_batch_u8()             # the GLOBAL batch, as Model._host_batch sees it
             lo, hi = parallel.shard_batch(X.shape[0], rank, world)
             taken.append(X[lo:hi])
         g.on_epoch_end()
