@@ -194,8 +194,10 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   can (the bf16-pipe conv kernels; every MFMA backward-weights kernel); the bn_bwd_apply pass (3 tensor passes per
  *   block) disappears.  Same two fmas per element as the stand-alone pass: bit-identical gradients.  The block's g buffer
  *   then keeps g' (oct_unet_debug_layer_fused tells which blocks).  0 = separate pass everywhere.
- *   "fuse_bn_finalize" (1): BN statistic partials are reduced to the layer's record by the LAST block of the launch that
- *   produces them (arrival counter; write-through partial rows) instead of by a bn_*_finalize launch.  0 = separate launch.
+ *   "fuse_bn_finalize" (0): 1 = the BN records of the thin layers (<= 32 channels) are written by the LAST block of the
+ *   launch that produces the partial rows (arrival counter; write-through rows; csrc/kernels_fin.hpp) instead of by a
+ *   bn_*_finalize launch.  Same results to fp32 rounding; measured 0.5-1 % slower per step than the launches it removes,
+ *   hence off by default.
  *   "dwbt_f32_all" (0): 1 = fp32 mode takes conv_dwbt_k for every thin backward-weights shape (default: where it wins).
  *   "dw_side_stream" (1): backward-weights kernels and the per-step weight preparation run on a low-priority stream
  *   owned by the handle, beside the backward-data chain.  0 = everything on the caller's stream.

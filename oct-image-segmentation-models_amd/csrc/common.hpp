@@ -73,7 +73,8 @@ __device__ inline void wave_reduce_multi(float (&v)[N]) {
 
 // Block (4 waves) reduction of N per-thread values -> out[0..N) written by threads 0..N-1.
 // `red` is 4*64 floats of LDS.  Contains two __syncthreads(); every thread of the block must call it.
-template <int N>
+// WT: the outputs are stored write-through (agent scope): rows another block of the same launch reads (kernels_fin.hpp).
+template <int N, bool WT = false>
 __device__ inline void block_reduce_store(float (&v)[N], float* red, float* out, int nvalid) {
     wave_reduce_multi<N>(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -81,7 +82,9 @@ __device__ inline void block_reduce_store(float (&v)[N], float* red, float* out,
     __syncthreads();
     if ((int)threadIdx.x < N && (int)threadIdx.x < nvalid) {
         const int l = threadIdx.x * (64 / N);
-        out[threadIdx.x] = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+        const float r = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+        if constexpr (WT) __hip_atomic_store(out + threadIdx.x, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[threadIdx.x] = r;
     }
     __syncthreads();
 }

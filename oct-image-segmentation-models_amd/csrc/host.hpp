@@ -34,7 +34,9 @@ struct Options {
     int fuse_bn_apply = 1;          // every other block: the transform is applied by the dX / dW kernels while they stage g'
     int fuse_dw_thin = 1;           // 3x3 layers with 8 output channels: backward-weights reduced inside the backward-data launches
     int timing_skip = 0;            // TIMING EXPERIMENTS ONLY (results become wrong): bit 0 / 1 = skip the forward / backward BN finalize launches after step 2
-    int fuse_bn_finalize = 1;       // BN statistic partials are finalized by the last block of the producing launch
+    int fuse_bn_finalize = 0;       // 1: the BN records of the thin layers are written by the last block of the launch that emits the
+                                    // partial rows (kernels_fin.hpp) instead of by a bn_*_finalize launch.  Built, tested -- and measured
+                                    // 0.5-1 % SLOWER per step than the 5 us finalize launches it removes: off
     int bt_m2 = 1;                  // conv_bt_k: 8-output-channel launches in the two-pixel form
     int dwbt_f32_all = 0;           // 1: fp32 mode also takes conv_dwbt_k for every thin shape
     int bt_blocks_per_cu = 0;       // thin bf16-pipe kernel: persistent blocks per CU (0 = what its LDS allows)

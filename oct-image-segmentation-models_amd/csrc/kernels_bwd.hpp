@@ -23,6 +23,7 @@ struct PoolBwdArgs {
     void* g;           // (B,H,W,C): in = decoder contribution (raw), out = masked total
     float* part;       // [B*tiles][2*C]   tiles over the POOLED grid
     int H, W, C, tiles_x, tiles, act_bf16;
+    FinDesc fin;       // pool_bwd_flat_k: BN-backward sums finalized by the last block (kernels_fin.hpp)
 };
 
 template <int C_T, typename AT>
@@ -145,9 +146,10 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_flat_k(const PoolBwdArgs A, i
     if (tid < A.C) {
         const int qq = tid >> 2, k = tid & 3;
         float* out = A.part + (size_t)blockIdx.x * (2 * A.C);
-        out[tid] = (sh[0][qq][k] + sh[1][qq][k]) + (sh[2][qq][k] + sh[3][qq][k]);           // fixed order
-        out[A.C + tid] = (sh[0][qq][4 + k] + sh[1][qq][4 + k]) + (sh[2][qq][4 + k] + sh[3][qq][4 + k]);
+        part_store(out + tid, (sh[0][qq][k] + sh[1][qq][k]) + (sh[2][qq][k] + sh[3][qq][k]));           // fixed order
+        part_store(out + A.C + tid, (sh[0][qq][4 + k] + sh[1][qq][4 + k]) + (sh[2][qq][4 + k] + sh[3][qq][4 + k]));
     }
+    if (A.fin.counter) finalize_in_launch(A.fin, A.part, gridDim.x, A.C, gridDim.x, reinterpret_cast<char*>(sh));
 }
 
 // ---- BN backward finalize + apply -------------------------------------------------------------------------------
@@ -155,21 +157,6 @@ struct BnBwdFinArgs {
     const float* part; int nblk, C; double count;
     float* bn; const float* gamma; float* dgamma; float* dbeta;
 };
-
-// partial sums (s = sum g', q = sum g' xhat) of channel c -> dbeta, dgamma, the record's c1, c2 and the two-fma form of the
-// BN-backward transform (common.hpp); thread 0 of whoever holds the sums (the finalize kernel, or the last block of the
-// producing launch)
-__device__ __forceinline__ void bn_bwd_finalize_write(double s, double q, double count, int C, int c, float* __restrict__ bn,
-                                                      const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                                      float* __restrict__ dbeta) {
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)q;
-    const double c1 = s / count, c2 = q / count;
-    const double rstd = (double)bn[BN_RSTD * C + c], mean = (double)bn[BN_MEAN * C + c];
-    const double ga = (double)gamma[c] * rstd, gb = -ga * rstd * c2, gd = -ga * c1 - gb * mean;
-    bn[BN_C1 * C + c] = (float)c1; bn[BN_C2 * C + c] = (float)c2;
-    bn[BN_GA * C + c] = (float)ga; bn[BN_GB * C + c] = (float)gb; bn[BN_GD * C + c] = (float)gd;
-}
 
 static __global__ __launch_bounds__(kBlock) void bn_bwd_finalize_k(const BnBwdFinArgs A) {
     __shared__ double sh[8];
@@ -246,6 +233,7 @@ struct HeadBwdArgs {
     // focal_dice_loss: L = w * focal + (1 - w) * dice  (focal_w = 0: plain Dice)
     float focal_w, focal_gamma; const float* focal_cw; float inv_count;   // inv_count = 1 / (B*H*W)
     int focal_clip_mod;                // see HeadFwdArgs
+    FinDesc fin;                       // BN-backward sums of the last conv block finalized by the last block (kernels_fin.hpp)
 };
 
 template <int C, int CIN, typename AT>
@@ -328,8 +316,8 @@ __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
     }
     const size_t row = (size_t)b * gridDim.x + blockIdx.x;
     float* out = A.part + row * (2 * CIN);
-    block_reduce_store<CP>(s1, red, out, CIN);
-    block_reduce_store<CP>(s2, red, out + CIN, CIN);
+    block_reduce_store<CP, true>(s1, red, out, CIN);
+    block_reduce_store<CP, true>(s2, red, out + CIN, CIN);
     float* wout = A.wpart + row * NV;
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
@@ -337,6 +325,10 @@ __global__ __launch_bounds__(kBlock) void head_bwd_k(const HeadBwdArgs A) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) t[k] = wv[gi * 32 + k];
         block_reduce_store<32>(t, red, wout + gi * 32, NV - gi * 32 < 32 ? NV - gi * 32 : 32);
+    }
+    if (A.fin.counter) {
+        __shared__ __attribute__((aligned(16))) char fin_lds[16 + kBlock * 16 + 2 * CP * 8];
+        finalize_in_launch(A.fin, A.part, gridDim.x * gridDim.y, CIN, gridDim.x * gridDim.y, fin_lds);
     }
 }
 

@@ -1358,8 +1358,10 @@ __global__ __launch_bounds__(kBlock, FDW ? 2 : (CT == 32 ? 1 : (CT == 16 ? 2 : 3
                     s += (red[(0 * 2 + stat) * MB + mh] + red[(1 * 2 + stat) * MB + mh]) +
                          (red[(2 * 2 + stat) * MB + mh] + red[(3 * 2 + stat) * MB + mh]);
                 }
-                if (ml < A.Mout) A.part[(size_t)blockIdx.x * (2 * A.Mout) + (size_t)stat * A.Mout + ml] = s;
+                if (ml < A.Mout) part_store(A.part + (size_t)blockIdx.x * (2 * A.Mout) + (size_t)stat * A.Mout + ml, s);
             }
+            // the last block of the launch turns the rows (one per block) into the layer's record (kernels_fin.hpp)
+            if (A.fin.counter) finalize_in_launch(A.fin, A.part, gridDim.x, A.Mout, gridDim.x, smem);
         }
     }
     if constexpr (FDW) {

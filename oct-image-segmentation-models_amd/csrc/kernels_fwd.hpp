@@ -6,6 +6,7 @@
 // affine (a, b) that bn_fwd_finalize derives from the conv's own per-block (sum, sum^2) partials.
 #pragma once
 #include "common.hpp"
+#include "kernels_fin.hpp"
 
 namespace oct {
 
@@ -23,6 +24,7 @@ struct ConvFwdArgs {
     int H, W, Cin, Cout, tiles_x, tiles;
     DropCfg drop;
     int act_bf16;      // activation storage type selector for the launcher
+    FinDesc fin;       // conv_first_fwd_k: statistics finalized by the last block of the launch (kernels_fin.hpp)
 };
 
 // acc[j] += sum_c f(src[pix][c]) * w[c][j]   (w row stride = Cout; all weight addresses wave-uniform)
@@ -182,8 +184,9 @@ __global__ __launch_bounds__(kBlock) void conv_first_fwd_k(const ConvFwdArgs A, 
     }
     if (A.part) {
         float* out = A.part + (size_t)blockIdx.x * 16;
-        block_reduce_store<8>(s1, red, out, 8);
-        block_reduce_store<8>(s2, red, out + 8, 8);
+        block_reduce_store<8, true>(s1, red, out, 8);
+        block_reduce_store<8, true>(s2, red, out + 8, 8);
+        if (A.fin.counter) finalize_in_launch(A.fin, A.part, gridDim.x, 8, gridDim.x, reinterpret_cast<char*>(Xs));      // (Xs: 5.2 KB, free now)
     }
 }
 
@@ -203,21 +206,7 @@ static __global__ __launch_bounds__(kBlock) void bn_fwd_finalize_k(const BnFinAr
     const int c = blockIdx.x;
     double s, q;
     column_sums_f64(A.part, A.nblk, A.C, c, sh, s, q);
-    if (threadIdx.x == 0) {
-        const double mean = s / A.count;
-        double var = q / A.count - mean * mean;
-        if (var < 0) var = 0;
-        const double rstd = 1.0 / sqrt(var + (double)A.eps);
-        const double a = (double)A.gamma[c] * rstd;
-        A.bn[BN_A * A.C + c] = (float)a;
-        A.bn[BN_B * A.C + c] = (float)((double)A.beta[c] - mean * a);
-        A.bn[BN_MEAN * A.C + c] = (float)mean;
-        A.bn[BN_RSTD * A.C + c] = (float)rstd;
-        const double m = A.momentum;
-        const double uv = (A.unbiased && A.count > 1) ? var * (A.count / (A.count - 1.0)) : var;
-        A.mm[c] = (float)((double)A.mm[c] * m + mean * (1.0 - m));
-        A.mv[c] = (float)((double)A.mv[c] * m + uv * (1.0 - m));
-    }
+    if (threadIdx.x == 0) bn_fwd_finalize_write(s, q, A.count, A.C, c, A.bn, A.gamma, A.beta, A.mm, A.mv, A.eps, A.momentum, A.unbiased);
 }
 
 // inference: (a, b) from the moving statistics, one thread per channel of one layer

@@ -17,6 +17,7 @@
 //   EPI_MASK (ReLU mask (+dropout) from the producer's z, BN-backward partial sums, store g').
 #pragma once
 #include "common.hpp"
+#include "kernels_fin.hpp"
 
 namespace oct {
 
@@ -55,10 +56,8 @@ struct IgemmArgs {
     // (rows a, b) -- the layer's partial-slab base [grid][9 * dw_Cin * Cin + Cin], the layer's input-channel count, this
     // slice's first input channel, and whether this launch also writes the bias-gradient column sums
     const void* dw_x; const float* dw_ab; float* dw_part; int dw_Cin, dw_ci_off, dw_bias;
-    unsigned* fin_counter;                       // statistics finalized in this launch (last block): arrival counter, or nullptr
-    const float* fin_gamma; const float* fin_beta; float* fin_bn; float* fin_mm; float* fin_mv;   // EPI_FWD: BnFinArgs fields
-    float* fin_dgamma; float* fin_dbeta;         // EPI_MASK: BnBwdFinArgs fields (fin_bn = producer's record, fin_gamma its gamma)
-    double fin_count; float fin_eps, fin_momentum; int fin_unbiased;
+    FinDesc fin;                                 // conv_bt_k: the statistics this launch emits (EPI_FWD: of its own output;
+                                                 // EPI_MASK: the BN-backward sums of the producer) are finalized by its last block
 };
 
 template <int SHAPE> struct MfmaShape;

@@ -223,6 +223,7 @@ struct oct_unet {
     float* params; float* grads; float* state;
     std::vector<void*> pooled, gpooled;    // per encoder level (activation storage type)
     float* stat_part = nullptr;            // BN statistic partials (fwd and bwd share it: stream-ordered)
+    unsigned* fin_counters = nullptr;      // [2 * layers] arrival counters of the in-launch finalizes (kernels_fin.hpp): zero between launches
     ReduceAllArgs red{};                   // filled while backward runs; one reduce launch at the end
     float* dice_part = nullptr; double* dice_bc = nullptr; float* loss4 = nullptr;   // loss4: 8 floats (dice_finalize_k)
     float focal_w = 0.f, focal_gamma = 2.f; const float* focal_cw = nullptr;           // focal_dice_loss (0 = plain Dice)
@@ -285,6 +286,8 @@ size_t carve(const oct_unet_cfg& c, Plan& pl, oct_unet* h, char* base, const Opt
     float* dp = (float*)take(B * nblk_head * 64 * 4);
     double* bc = (double*)take((B * 8 * 2 + 2) * 8);
     float* l4 = (float*)take(8 * 4);
+    unsigned* fc = (unsigned*)take(2 * pl.L.size() * sizeof(unsigned));
+    if (h) h->fin_counters = fc;
     WtDesc* wd = c.training ? (WtDesc*)take(pl.L.size() * sizeof(WtDesc)) : nullptr;
     WbxDesc* xd = (WbxDesc*)take(2 * pl.L.size() * sizeof(WbxDesc));
     WbtDesc* td = (WbtDesc*)take(3 * pl.L.size() * sizeof(WbtDesc));
@@ -300,6 +303,20 @@ DropCfg make_drop(const oct_unet* h) {
     d.thresh = (unsigned)std::min(4294967295.0, std::floor(r * 4294967296.0));
     d.scale = (float)(1.0 / (1.0 - r));
     return d;
+}
+
+// statistics of block li finalized by the last block of the launch that emits them (kernels_fin.hpp): thin channel counts
+// only -- the reduction is done by ONE block
+inline bool fin_ok(const oct_unet* h, const Layer& l) { return h->opt.fuse_bn_finalize && l.has_bn && l.cout <= 32 && l.cout % 2 == 0; }
+FinDesc fin_desc(const oct_unet* h, int li, int bwd, int B) {
+    const Layer& l = h->plan.L[li];
+    FinDesc f{};
+    f.counter = h->fin_counters + 2 * li + (bwd ? 1 : 0); f.bwd = bwd; f.count = (double)B * l.H * l.W;
+    f.bn = l.bn; f.gamma = h->params + l.gamma_off; f.beta = h->params + l.beta_off;
+    f.mm = h->state + l.mm_off; f.mv = h->state + l.mv_off;
+    f.eps = h->cfg.bn_eps; f.momentum = h->cfg.bn_momentum; f.unbiased = h->cfg.bn_unbiased_moving_var;
+    if (bwd) { f.dgamma = h->grads + l.gamma_off; f.dbeta = h->grads + l.beta_off; }
+    return f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -364,6 +381,7 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
     const double by = in_bytes(l, B, x_is_u8, es) + px * l.cout * es;   // logical input once + output once
     int rc;
     int stat_rows = B * a.tiles;
+    bool fin_in_launch = false;
     if (l.src != SRC_INPUT && l.cin % 4 == 0) {   // MFMA path (every conv except the 1-channel first layer)
         IgemmArgs g{};
         g.x0 = sd.x0; g.ab0 = sd.ab0; g.C0 = sd.C0; g.x1 = sd.x1; g.ab1 = sd.ab1; g.C1 = sd.C1;
@@ -373,12 +391,14 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
         g.part = a.part; g.drop = a.drop; g.act_bf16 = h->cfg.dtype;
         g.wbx = l.wbx_f; g.wbx_M = l.cout; g.wbt = l.wbt_f; g.bt_m2 = l.bt_m2_f;
         const LaunchCtx lc{&h->opt, B, s, l.name, fl, by};
+        if (training && fin_ok(h, l) && conv_route(g, l.src == SRC_UP ? A_UPF : A_NORMAL, h->opt) == ROUTE_BT) { g.fin = fin_desc(h, li, 0, B); fin_in_launch = true; }
         rc = l.src == SRC_UP ? launch_igemm<2, A_UPF, EPI_FWD>(g, lc, &stat_rows)
                              : launch_igemm<3, A_NORMAL, EPI_FWD>(g, lc, &stat_rows);
     } else if (l.src == SRC_INPUT && l.cin == 1 && l.cout == 8 && l.kh == 3) {   // the real first layer: persistent streaming kernel
         const int tx = cdiv(l.W, 128), tiles = tx * cdiv(l.H, 8), total = B * tiles;
         const int grid = std::min(total, 2048);      // <= B*ceil(H/2)*ceil(W/32) statistic rows guaranteed by carve()
         const int bf = h->cfg.dtype;
+        if (training && fin_ok(h, l)) { a.fin = fin_desc(h, li, 0, B); fin_in_launch = true; }
         ProfScope ps(s, bf ? "conv_first_fwd_k<unsigned short>" : "conv_first_fwd_k<float>", l.name, fl, by);
         AT_DISPATCH(bf, conv_first_fwd_k<AT><<<grid, kBlock, 0, s>>>(a, x_is_u8, tx, tiles, total, a.w, a.bias));
         HIP_OK(hipGetLastError());
@@ -389,7 +409,7 @@ int conv_forward(oct_unet* h, int li, const void* x_in, int x_is_u8, int B, int 
         return fail(-3, "conv_forward: channel count not a multiple of 4");
     }
     if (rc) return rc;
-    if (l.has_bn && training && !(h->opt.timing_skip & 1 && h->drop_step > 2)) {
+    if (l.has_bn && training && !fin_in_launch && !(h->opt.timing_skip & 1 && h->drop_step > 2)) {
         ProfScope ps(s, "bn_fwd_finalize_k", l.name, 0, (double)stat_rows * 2 * l.cout * 4);
         BnFinArgs f{};
         f.part = h->stat_part; f.nblk = stat_rows; f.C = l.cout; f.count = (double)B * l.H * l.W;
@@ -679,6 +699,8 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     }
     if (side_ok) HIP_OK(hipEventRecord(h->prep_ev, h->side));
     bool prep_pending = side_ok;
+    bool pending_fin = false;                 // the pending statistics were finalized by the launch that emitted them
+    if (fin_ok(h, last)) { hb.fin = fin_desc(h, nl - 2, 1, B); pending_fin = true; }
     int rc = DISPATCH_C(launch_head_bwd, h->cfg.n_cls, hb, hd.cin, B, s);
     if (rc) return rc;
     int pending_nblk = B * hb.nblk;           // number of stat partial rows waiting for block (li-1)
@@ -722,8 +744,9 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
                    (l.src != SRC_CONCAT || conv_route(dx_args(nullptr, cg, cg, nullptr, false), A_NORMAL, o) != ROUTE_F32);
         }
         l.g_masked = fuse;
-        rc = bn_backward(h, li, pending_nblk, B, s, fuse, false);
+        rc = bn_backward(h, li, pending_nblk, B, s, fuse, pending_fin);
         if (rc) return rc;
+        pending_fin = false;
         // 3x3 layers with 8 output channels on the thin kernel (the full-resolution convs): their backward-data launches
         // reduce the backward-weights too (conv_bt_k FDW) -- g', z and the producer's z are read once for both
         bool fdw = false;
@@ -770,6 +793,9 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
                 fl *= 2; if (!prod) by += pxg * Cg * es;                      // + the dW flops; + the X read where no mask reads it
             }
             const LaunchCtx lc{&o, B, s, l.name, fl, by};
+            if (prod && fin_ok(h, *prod) && conv_route(g, up ? A_DOWN2 : A_NORMAL, o) == ROUTE_BT) {
+                g.fin = fin_desc(h, (int)(prod - pl.L.data()), 1, B); pending_fin = true;
+            }
             if (up) return launch_igemm<3, A_DOWN2, EPI_MASK>(g, lc, &rows);
             return prod ? launch_igemm<3, A_NORMAL, EPI_MASK>(g, lc, &rows)
                         : launch_igemm<3, A_NORMAL, EPI_RAW>(g, lc, &rows);
@@ -796,6 +822,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
                     const size_t items = (size_t)B * (p.H / 2) * (p.W / 2) * c4;
                     const size_t cap = (size_t)B * cdiv(p.H, 2) * cdiv(p.W, kTileX);     // statistic rows carve() guarantees
                     const int grid = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(cdiv((int)items, kBlock), 2048), cap));
+                    if (fin_ok(h, p)) { pb.fin = fin_desc(h, li - 1, 1, B); pending_fin = true; }
                     ProfScope ps(s, bf ? "pool_bwd_flat_k<unsigned short>" : "pool_bwd_flat_k<float>", p.name, 0, pbytes);
                     AT_DISPATCH(bf, pool_bwd_flat_k<AT><<<grid, kBlock, 0, s>>>(pb, B));
                     HIP_OK(hipGetLastError());
@@ -966,6 +993,10 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
             hipError_t e = hipMemcpy(h->wbt_descs, d.data(), d.size() * sizeof(WbtDesc), hipMemcpyHostToDevice);
             if (e != hipSuccess) { delete h; return fail(-5, std::string("hipMemcpy(wbt_descs): ") + hipGetErrorString(e)); }
         }
+    }
+    {
+        hipError_t e0 = hipMemset(h->fin_counters, 0, 2 * h->plan.L.size() * sizeof(unsigned));
+        if (e0 != hipSuccess) { delete h; return fail(-5, std::string("hipMemset(fin_counters): ") + hipGetErrorString(e0)); }
     }
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);

@@ -268,3 +268,48 @@ def test_configs2_bf16_at_batch_64_full_size():
     eng.set_dropout_step(2)
     eng.forward(x, training=True, labels=l, want_probs=False); eng.loss_dice(); eng.backward(l, macro=True)
     assert torch.equal(eng.grads, g1)
+
+
+def test_statistics_finalized_in_the_producing_launch_agree_with_the_finalize_kernels_over_many_steps():
+    """Option "fuse_bn_finalize": the BatchNorm records of the thin layers are written by the LAST block of the launch that
+    emits the partial rows (write-through rows + arrival counter, csrc/kernels_fin.hpp) instead of by a bn_*_finalize launch.  A hand-off between
+    workgroups of one launch that went wrong would show as a stale / partial sum in SOME step under load, so: 25 training
+    steps at the benched configuration (B = 32, every CU busy, 768-block persistent grids), each compared with an engine
+    that runs the separate finalize kernels on identical inputs and parameters -- records and moving statistics to fp32
+    rounding (the two routes add the same rows in different orders), and the finalize launches of those layers are gone."""
+    from oct_image_segmentation_models_amd import _hip
+    from oct_image_segmentation_models_amd.engine import UNetEngine
+    B = 32
+    img, lab = scans(B, 51)
+    x = torch.from_numpy(img).cuda(); l = torch.from_numpy(lab[..., 0].copy()).cuda()
+    engs = {}
+    try:
+        for fused in (1, 0):
+            _hip.set_option("fuse_bn_finalize", fused)
+            engs[fused] = UNetEngine(device="cuda:0", input_channels=1, num_classes=C, image_height=H, image_width=W,
+                                     max_batch=B, training=True, seed=5, init_seed=3)
+    finally:
+        _hip.set_option("fuse_bn_finalize", 0)          # (the default: the route measured 0.5-1 % slower per step, DESIGN.md section 10)
+    nb = len(engs[1].layers) - 1
+    for step in range(25):
+        recs = {}
+        for fused, eng in engs.items():
+            eng.set_dropout_step(step)
+            if step == 0:
+                eng.profile_begin()
+            eng.forward(x, training=True, labels=l, want_probs=False); eng.loss_dice(); eng.backward(l, macro=True)
+            if step == 0:
+                fins = [e for e in eng.profile_end() if e["kernel"].startswith("bn_") and "finalize" in e["kernel"]]
+                n = sum(e["launches"] for e in fins)
+                assert (n <= 2 * nb - 18) if fused else (n == 2 * nb), (fused, n)        # >= 18 of the 44 launches are gone
+            recs[fused] = ([eng.debug_bn_record(li).clone() for li in range(nb)], eng.state.clone(), eng.grads.clone())
+            eng.adam_step(lr=1e-3)
+        engs[0].params.copy_(engs[1].params)          # keep the two engines on identical parameters
+        engs[0].state.copy_(engs[1].state)
+        for li in range(nb):
+            a, b = recs[1][0][li].double(), recs[0][0][li].double()
+            scale = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+            assert ((a - b).abs() / scale).max() < 2e-5, (step, engs[1].layers[li]["name"], ((a - b).abs() / scale).amax(dim=1))
+        assert (recs[1][1] - recs[0][1]).abs().max() < 1e-6 * max(1.0, float(recs[0][1].abs().max()))
+        g1, g0 = recs[1][2].double(), recs[0][2].double()
+        assert (g1 - g0).norm() <= 1e-4 * g0.norm(), step

@@ -58,7 +58,7 @@ DROP_STEP = 3
 
 @pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111", "dw16_padded",
                         "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all", "bt_one_px", "bn_apply_separate",
-                        "bn_finalize_separate", "bx_one_block", "dw_thin_separate"])
+                        "bn_finalize_in_launch", "bx_one_block", "dw_thin_separate"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant: for the thin layers the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels (otherwise only chosen on large grids); for the wide layers the
@@ -75,7 +75,7 @@ def variant(request):
     _hip.set_option("bt_m2", 0 if v == "bt_one_px" else 1)           # thin kernel: 8-channel launches without the two-pixel form
     _hip.set_option("fuse_first_apply", 0 if v == "bn_apply_separate" else 1)   # bn_bwd_apply as its own pass: block 0 ...
     _hip.set_option("fuse_bn_apply", 0 if v == "bn_apply_separate" else 1)      # ... and every other block
-    _hip.set_option("fuse_bn_finalize", 0 if v == "bn_finalize_separate" else 1)   # bn_*_finalize as their own launches
+    _hip.set_option("fuse_bn_finalize", 1 if v == "bn_finalize_in_launch" else 0)   # thin layers' BN records written by the last block of the producing launch
     _hip.set_option("fuse_dw_thin", 0 if v == "dw_thin_separate" else 1)   # 8-channel 3x3 layers: backward-weights as their own kernel
     _hip.set_option("igemm_persistent_min_tiles", 1 if v == "persistent" else 1 << 30)
     _hip.set_option("thin8_min_tiles", 1 if v == "thin8_valu" or v.startswith("pair8") else 1 << 30)
@@ -91,7 +91,7 @@ def variant(request):
     _hip.set_option("bt_m2", 1)
     _hip.set_option("fuse_first_apply", 1)
     _hip.set_option("fuse_bn_apply", 1)
-    _hip.set_option("fuse_bn_finalize", 1)
+    _hip.set_option("fuse_bn_finalize", 0)
     _hip.set_option("fuse_dw_thin", 1)
     _hip.set_option("dwpair8_enable", 1)
     _hip.set_option("igemm_persistent_min_tiles", 2048)
