@@ -737,10 +737,12 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             const int cg = bx_bwd_cg(l);
             const bool up = l.src == SRC_UP;
             const ConvRoute r0 = conv_route(dx_args(nullptr, cg, 0, nullptr, up), up ? A_DOWN2 : A_NORMAL, o);
-            // (two bf16-pipe instantiations stay out: the stride-2 gather beyond the coefficient rows its LDS holds, and the
-            //  thin kernel at 32 K channels, whose staging registers for g' AND z no longer fit)
+            // (three bf16-pipe instantiations stay out: the stride-2 gather beyond the coefficient rows its LDS holds; the
+            //  thin kernel at 32 K channels, whose staging registers for g' AND z no longer fit; and the thin kernel at 16 K
+            //  channels with 16 output channels, where the second raw register set spills under the 256-register budget of two
+            //  blocks per CU: 87 us against 45 + 33 for the separate pass at B = 32, 128 x 256)
             fuse = o.fuse_bn_apply && dwkind != 0 && r0 != ROUTE_F32 && !(up && r0 == ROUTE_BX && l.cout > kBxGbDown2MaxC) &&
-                   !(r0 == ROUTE_BT && l.cout == 32) &&
+                   !(r0 == ROUTE_BT && l.cout == 32) && !(r0 == ROUTE_BT && l.cout == 16 && cg == 16) &&
                    (l.src != SRC_CONCAT || conv_route(dx_args(nullptr, cg, cg, nullptr, false), A_NORMAL, o) != ROUTE_F32);
         }
         l.g_masked = fuse;
