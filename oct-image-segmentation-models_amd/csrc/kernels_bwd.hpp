@@ -1,12 +1,15 @@
 // Backward kernels.
 //
-// Gradient flow contract: for a conv block  z = conv(x)+bias, y = relu(BN(z)):
+// Gradient flow contract (DESIGN.md sections 5, 10): for a conv block  z = conv(x)+bias, y = relu(BN(z)):
 //   * whoever produces dL/dy writes g' = dL/dy * [y>0] (* dropout) into the block's g buffer and emits
 //     per-block partials of  sum(g')  and  sum(g' * xhat)  (the two BN-backward reductions = dbeta, dgamma);
-//   * bn_bwd_finalize turns the partials into c1 = sum(g')/N, c2 = sum(g' xhat)/N and dgamma/dbeta;
-//   * bn_bwd_apply rewrites g' in place into dz = gamma*rstd*(g' - c1 - xhat*c2);
-//   * the dW kernels (kernels_dw.hpp) reduce dW = sum x (x) dz; backward-data runs through the implicit-GEMM /
-//     thin-layer conv kernels (kernels_igemm.hpp, kernels_thin.hpp) with transposed / effective weights.
+//   * bn_bwd_finalize turns the partials into c1 = sum(g')/N, c2 = sum(g' xhat)/N, dgamma/dbeta and the two-fma form
+//     dz = ga g' + (gb z + gd) of the BN-backward transform (record rows ga, gb, gd; common.hpp);
+//   * the consumers of dz -- the backward-data launches (kernels_bx.hpp) and the backward-weights kernels (kernels_dw.hpp,
+//     kernels_bx.hpp) -- apply that transform themselves while they stage g' and z (dz is never stored); bn_bwd_apply, which
+//     rewrites g' in place into dz, runs only for the blocks whose consumers cannot (fp32-pipe conv kernels, two thin-kernel
+//     instantiations): same two fmas, bit-identical results;
+//   * the dW kernels reduce dW = sum x (x) dz into one partial slab per block; reduce_all_k sums the slabs.
 #pragma once
 #include "common.hpp"
 #include "kernels_fwd.hpp"
