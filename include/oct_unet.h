@@ -201,6 +201,10 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   "dwbt_f32_all" (0): 1 = fp32 mode takes conv_dwbt_k for every thin backward-weights shape (default: where it wins).
  *   "dw_side_stream" (1): backward-weights kernels and the per-step weight preparation run on a low-priority stream
  *   owned by the handle, beside the backward-data chain.  0 = everything on the caller's stream.
+ *   "fork_on_launch" (1): the event such a backward-weights kernel waits for is the completion signal of the preceding
+ *   launch itself (hipExtLaunchKernelGGL stopEvent) rather than a marker recorded behind it.  "dw_fork_group" (1): blocks
+ *   whose backward-weights launches share one fork (2-4: fewer waits on the caller's stream, measured slower overall).
+ *   "event_sysfence" (0; read at oct_unet_create): 1 = the handle's internal fork/join events carry a system-scope fence.
  *   "igemm_persistent_min_tiles" (default 2048): number of pixel tiles from which thin single-chunk convs use the
  *   persistent software-pipelined kernel instead of the one-tile-per-block kernel.
  *   "thin8_min_tiles" (default 2048): number of pixel tiles from which 8-output-channel convs run on the VALU

@@ -45,6 +45,12 @@ struct Options {
     int bx_min_blocks = 256;        // a bf16-pipe launch takes the taller pixel tile only if that still yields this many blocks
     int mfma_mode = 1;              // 1: bf16 MFMA pipe (split products in fp32 mode); 0: the fp32-pipe kernels everywhere
     int focal_clip_mod = 0;         // focal loss: 1 = the (1-p)^gamma modulation sees the clipped p too
+    int fork_on_launch = 1;         // the event a forked backward-weights kernel waits for is the completion signal of the preceding
+                                    // launch itself (0: a recorded marker behind it -- ~6 us in front of every backward-data launch)
+    int dw_fork_group = 1;          // blocks whose backward-weights launches share one fork to the side stream.  Measured: 2-4 halve the
+                                    // caller stream's idle time (119 -> 71 us) and still lose 1.3-1.7 % per step -- the late kernels
+                                    // pair with backward-data launches of the next level, which they slow down more
+    int event_sysfence = 0;         // 1: the handle's fork/join events carry a system-scope fence (set before oct_unet_create)
     int persist_min_tiles = 2048;   // pixel tiles from which thin single-chunk convs use the persistent pipelined kernel
 };
 extern Options g_opt;

@@ -1,6 +1,7 @@
 // liboct_unet_hip.so -- host plan + C ABI of the MI355X-native OCT U-Net engine.  See include/oct_unet.h.
 // Graph definition follows /root/reference/oct_image_segmentation_models/models/unet.py:106-153.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -638,14 +639,26 @@ int conv_backward_w(oct_unet* h, int li, const void* x_in, int x_is_u8, const vo
 
 // finalize (and, unless the consumers apply it on load, apply) BN backward for block li: its g buffer holds masked
 // gradients, stat_part the partials
-int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s, bool finalize_only, bool finalized_in_launch) {
+// `done` (optional): an event that must complete when the block's dz inputs are final.  It is bound to the LAST kernel
+// launched here as that dispatch's own completion signal (hipExtLaunchKernelGGL's stopEvent) instead of being recorded
+// behind it: a recorded event is a marker packet of its own in the stream, and the next backward-data launch waits
+// ~6 us for the command processor to retire it -- on every block that forks a backward-weights kernel.  *bound = false
+// when nothing was launched (the caller then records the event the ordinary way).
+int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s, bool finalize_only, bool finalized_in_launch,
+                hipEvent_t done = nullptr, bool* bound = nullptr) {
     const Layer& l = h->plan.L[li];
+    if (bound) *bound = false;
     if (!finalized_in_launch && !(h->opt.timing_skip & 2 && h->drop_step > 2)) {
         BnBwdFinArgs f{};
         f.part = h->stat_part; f.nblk = nblk; f.C = l.cout; f.count = (double)B * l.H * l.W;
         f.bn = l.bn; f.gamma = h->params + l.gamma_off; f.dgamma = h->grads + l.gamma_off; f.dbeta = h->grads + l.beta_off;
         ProfScope ps(s, "bn_bwd_finalize_k", l.name, 0, (double)nblk * 2 * l.cout * 4);
-        bn_bwd_finalize_k<<<l.cout, kBlock, 0, s>>>(f);
+        if (done && finalize_only) {
+            hipExtLaunchKernelGGL(bn_bwd_finalize_k, dim3(l.cout), dim3(kBlock), 0, s, nullptr, done, 0, f);
+            if (bound) *bound = true;
+        } else {
+            bn_bwd_finalize_k<<<l.cout, kBlock, 0, s>>>(f);
+        }
         HIP_OK(hipGetLastError());
     }
     if (finalize_only) return 0;      // the consumers apply the transform themselves
@@ -656,12 +669,24 @@ int bn_backward(oct_unet* h, int li, int nblk, int B, hipStream_t s, bool finali
         const size_t n8 = n4 / 2;
         const int grid8 = (int)std::min<size_t>((n8 + kBlock - 1) / kBlock, 8192);
         ProfScope ps(s, "bn_bwd_apply8_bf16_k", l.name, 0, (double)n4 * 8 * 3);
-        bn_bwd_apply8_bf16_k<<<grid8, kBlock, 0, s>>>((bf16_t*)l.g, (const bf16_t*)l.z, l.bn, n8, l.cout);
+        if (done) {
+            hipExtLaunchKernelGGL(bn_bwd_apply8_bf16_k, dim3(grid8), dim3(kBlock), 0, s, nullptr, done, 0,
+                                  (bf16_t*)l.g, (const bf16_t*)l.z, (const float*)l.bn, n8, l.cout);
+            if (bound) *bound = true;
+        } else {
+            bn_bwd_apply8_bf16_k<<<grid8, kBlock, 0, s>>>((bf16_t*)l.g, (const bf16_t*)l.z, l.bn, n8, l.cout);
+        }
         HIP_OK(hipGetLastError());
         return 0;
     }
     ProfScope ps(s, bf ? "bn_bwd_apply_k<unsigned short>" : "bn_bwd_apply_k<float>", l.name, 0, (double)n4 * (bf ? 8 : 16) * 3);
-    AT_DISPATCH(bf, bn_bwd_apply_k<AT><<<grid, kBlock, 0, s>>>((AT*)l.g, (const AT*)l.z, l.bn, n4, l.cout));
+    if (done) {
+        AT_DISPATCH(bf, hipExtLaunchKernelGGL(bn_bwd_apply_k<AT>, dim3(grid), dim3(kBlock), 0, s, nullptr, done, 0,
+                                              (AT*)l.g, (const AT*)l.z, (const float*)l.bn, n4, l.cout));
+        if (bound) *bound = true;
+    } else {
+        AT_DISPATCH(bf, bn_bwd_apply_k<AT><<<grid, kBlock, 0, s>>>((AT*)l.g, (const AT*)l.z, l.bn, n4, l.cout));
+    }
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -705,6 +730,9 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
     if (rc) return rc;
     int pending_nblk = B * hb.nblk;           // number of stat partial rows waiting for block (li-1)
     bool forked = false;
+    struct PendingDw { int li; bool fuse; };
+    std::vector<PendingDw> pend;          // forked backward-weights launches not yet issued
+    unsigned n_forks = 0;
     h->red.n = 0;
     queue_reduce(h, hd, pending_nblk);   // head kernel/bias gradient rows written by head_bwd_k
 
@@ -746,9 +774,6 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
                    (l.src != SRC_CONCAT || conv_route(dx_args(nullptr, cg, cg, nullptr, false), A_NORMAL, o) != ROUTE_F32);
         }
         l.g_masked = fuse;
-        rc = bn_backward(h, li, pending_nblk, B, s, fuse, pending_fin);
-        if (rc) return rc;
-        pending_fin = false;
         // 3x3 layers with 8 output channels on the thin kernel (the full-resolution convs): their backward-data launches
         // reduce the backward-weights too (conv_bt_k FDW) -- g', z and the producer's z are read once for both
         bool fdw = false;
@@ -757,20 +782,36 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             conv_route(dx_args(nullptr, 8, 0, nullptr, false), A_NORMAL, o) == ROUTE_BT &&
             (l.src != SRC_CONCAT || conv_route(dx_args(nullptr, 8, 8, nullptr, false), A_NORMAL, o) == ROUTE_BT))
             fdw = true;
-        const bool fork = side_ok && !fdw;     // (the per-launch profiler wants serial launches)
-        if (fdw) {
-            // nothing here: the slabs are written by the backward-data launches below
-        } else if (fork) {
-            hipEvent_t e = h->fork_ev[1 + li % (h->fork_ev.size() - 1)];
-            HIP_OK(hipEventRecord(e, s));                        // dz of block li is final here
-            HIP_OK(hipStreamWaitEvent(h->side, e, 0));
-            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, h->side, fuse);
-            forked = true;
-        } else {
-            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s, fuse);
-        }
+        // (the per-launch profiler wants serial launches; the input layer has no backward-data launch to run beside, so its
+        //  backward-weights kernel stays on the caller's stream: no fork, no join wait in front of the slab reduce)
+        const bool fork = side_ok && !fdw && l.src != SRC_INPUT;
+        // Forked backward-weights launches go to the side stream in GROUPS (dw_fork_group blocks per fork): every event the
+        // side stream waits for costs the caller's stream ~6 us in front of its next launch (the dispatch that carries the
+        // completion signal has to be retired by the command processor first), and a block's dz, z and record stay valid
+        // until the end of the backward pass, so its backward-weights kernel may start a block or two late.
+        const bool tail_here = h->tail_event && li == first_mid_layer(pl);
+        if (fork) pend.push_back({li, fuse});
+        const bool flush = !pend.empty() && (!fork || (int)pend.size() >= o.dw_fork_group || tail_here);
+        hipEvent_t fe = flush ? h->fork_ev[1 + n_forks++ % (h->fork_ev.size() - 1)] : nullptr;
+        bool fe_bound = false;
+        rc = bn_backward(h, li, pending_nblk, B, s, fuse, pending_fin, (flush && o.fork_on_launch) ? fe : nullptr, &fe_bound);
         if (rc) return rc;
-        if (h->tail_event && li == first_mid_layer(pl)) {
+        pending_fin = false;
+        if (flush) {
+            if (!fe_bound) HIP_OK(hipEventRecord(fe, s));        // dz of every pending block is final here
+            HIP_OK(hipStreamWaitEvent(h->side, fe, 0));
+            for (const PendingDw& p : pend) {
+                rc = conv_backward_w(h, p.li, x_in, x_is_u8, pl.L[p.li].g, B, h->side, p.fuse);
+                if (rc) return rc;
+            }
+            pend.clear();
+            forked = true;
+        }
+        if (!fdw && !fork) {
+            rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s, fuse);
+            if (rc) return rc;
+        }
+        if (tail_here) {
             if (forked) { HIP_OK(hipEventRecord(h->join_ev, h->side)); HIP_OK(hipStreamWaitEvent(s, h->join_ev, 0)); }
             // every parameter gradient at offsets >= L[li].w_off (bottleneck, decoder, head: Keras creation order) is
             // final once the queued slabs are summed: the DP launcher all-reduces that segment on a side stream while
@@ -1010,9 +1051,12 @@ int oct_unet_create(const oct_unet_cfg* c, float* params, float* grads, float* s
         if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) h->side = nullptr;
         if (h->side) {
             h->fork_ev.resize(9);
-            bool ok = hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming) == hipSuccess &&
-                      hipEventCreateWithFlags(&h->prep_ev, hipEventDisableTiming) == hipSuccess;
-            for (auto& e : h->fork_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            // the events order work between two streams of ONE device: no system-scope fence (an L2 write-back in front of
+            // the next launch, which reads these layers' tensors from L2) unless asked for
+            const unsigned evf = hipEventDisableTiming | (h->opt.event_sysfence ? 0u : (unsigned)hipEventDisableSystemFence);
+            bool ok = hipEventCreateWithFlags(&h->join_ev, evf) == hipSuccess &&
+                      hipEventCreateWithFlags(&h->prep_ev, evf) == hipSuccess;
+            for (auto& e : h->fork_ev) ok = ok && hipEventCreateWithFlags(&e, evf) == hipSuccess;
             if (!ok) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
         }
     }
@@ -1221,7 +1265,8 @@ const Opt k_opts[] = {
     {"fuse_bn_finalize", &Options::fuse_bn_finalize, 0, 1}, {"bx_waves", &Options::bx_waves, 4, 8},
     {"dw_side_stream", &Options::dw_side_stream, 0, 1}, {"timing_skip", &Options::timing_skip, 0, 255}, {"fuse_dw_thin", &Options::fuse_dw_thin, 0, 1},
     {"dwbx_enable", &Options::dwbx_enable, 0, 1},
-    {"bx_two_blocks", &Options::bx_two_blocks, 0, 1},
+    {"bx_two_blocks", &Options::bx_two_blocks, 0, 1}, {"fork_on_launch", &Options::fork_on_launch, 0, 1},
+    {"event_sysfence", &Options::event_sysfence, 0, 1}, {"dw_fork_group", &Options::dw_fork_group, 1, 8},
 };
 }  // namespace
 
