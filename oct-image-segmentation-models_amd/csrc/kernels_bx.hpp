@@ -386,6 +386,28 @@ __global__ __launch_bounds__(64 * NW, NIMG == 1 ? (NW == 4 ? 2 : 1) : 1) void co
             }
 #endif
         }
+#if !defined(BX_NOPIN)
+        // Pin the order: left alone, hipcc sinks every fragment read to just in front of its first MFMA and waits
+        // lgkmcnt(0) there -- an LDS round trip in front of every one to six MFMAs.  Tap 0's fragments first; then the reads
+        // of tap kx+1 go between the MFMAs of tap kx, one group per MFMA.
+        if constexpr (!decltype(do_store)::value) {
+            constexpr int RD = (MTW + NTW) * NS, MF = MTW * NTW * (NS == 3 ? 6 : 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+            for (int kx = 0; kx < KH; ++kx) {
+                if (kx + 1 < KH) {
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i < RD % MF) __builtin_amdgcn_sched_group_barrier(0x100, RD / MF + 1, 0);
+                        else if (RD / MF > 0) __builtin_amdgcn_sched_group_barrier(0x100, RD / MF, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+                }
+            }
+        }
+#endif
     };
 
     // ---- pipeline over (chunk, tap row) ----
@@ -446,7 +468,17 @@ __global__ __launch_bounds__(64 * NW, NIMG == 1 ? (NW == 4 ? 2 : 1) : 1) void co
         }
     };
     int g = 0;
-    for (int c = 0; c < nch; ++c) {
+#if defined(BX_DBG) && (BX_DBG == 6 || BX_DBG == 7)      // timing experiments: prologue + epilogue only (6), prologue only (7)
+    const int nch_run = 0;
+    if constexpr (NW == 4) load_zraw();
+    load_epi();
+#if BX_DBG == 7
+    if (A.Cin > 0) return;
+#endif
+#else
+    const int nch_run = nch;
+#endif
+    for (int c = 0; c < nch_run; ++c) {
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky, ++g) {
             const bool last_row = ky == KH - 1, more = c + 1 < nch;
@@ -464,7 +496,7 @@ __global__ __launch_bounds__(64 * NW, NIMG == 1 ? (NW == 4 ? 2 : 1) : 1) void co
                     touch_raw(pin[k][0]); touch_raw(pin[k][1]);
                     if constexpr (GB) { touch_raw(pz[k][0]); touch_raw(pz[k][1]); }
                 }
-                begin_store((c + 1) * 16);
+                if constexpr (NIMG == 2) begin_store((c + 1) * 16);     // (one image: after the sweep -- 16-24 registers less in it)
             }
 #if !(defined(BX_DBG) && BX_DBG == 5)      // (5: timing experiment without the in-loop weight DMA)
             if (!last_row) dma_slab(c, ky + 1, (g + 1) & 1);
@@ -477,6 +509,7 @@ __global__ __launch_bounds__(64 * NW, NIMG == 1 ? (NW == 4 ? 2 : 1) : 1) void co
             } else {
                 sweep_row(ky, g & 1, 0, std::false_type{}, 0);
                 if (last_row && more) {          // every wave is done with the image: overwrite it with the next K chunk
+                    begin_store((c + 1) * 16);
                     __syncthreads();
 #pragma unroll
                     for (int k = 0; k < NSLOT; ++k) store_slot(k, 0);

@@ -140,11 +140,15 @@ __device__ __forceinline__ void bias_reduce(const ConvBwdWArgs& A, float* scratc
 // Every wave owns ALL M tiles for a quarter of the tile's pixel rows; 4-wave sum through LDS at the end.
 // grid (npb, ceil(Cin/CIC), ceil(Cout/16))
 // ---------------------------------------------------------------------------------------------------------------
-template <int KH, int CIC, bool UP, typename AT, bool GB = false>
-__global__ __launch_bounds__(kBlock, 3) void conv_dw16_k(const ConvBwdWArgs A) {   // 3 waves/SIMD: <= 168 VGPRs
+// DC = channels of dz that are STAGED (16, or 8 for layers with 8 output channels): with DC = 8 a pixel of the dz tile
+// is 8 floats, lanes 8-15 of a B operand read the next pixel's channels (finite values: they fill MFMA columns 8-15,
+// which are never written out), no staging slot and no prefetch register is spent on absent channels.
+template <int KH, int CIC, bool UP, typename AT, bool GB = false, int DC = 16>
+__global__ __launch_bounds__(kBlock, DC == 8 ? 4 : 3) void conv_dw16_k(const ConvBwdWArgs A) {   // 3 (4) waves/SIMD: <= 168 (128) VGPRs
     constexpr int TH = 8, TW = 32, TAPS = KH * KH, MROWS = TAPS * CIC, MTILES = (MROWS + 15) / 16;
     constexpr int IH = UP ? TH / 2 + 1 : TH + KH - 1, IW = UP ? TW / 2 + 1 : TW + KH - 1;
-    constexpr int XS = IH * IW * CIC, DS = TH * TW * 16, RED = 4 * MTILES * 256;
+    constexpr int XS = IH * IW * CIC, DS = TH * TW * DC + (16 - DC), RED = 4 * MTILES * 256;
+    static_assert(DC == 16 || DC == 8, "dz staging width");
     constexpr int LDSN = (XS + DS > RED ? XS + DS : RED) > 1024 ? (XS + DS > RED ? XS + DS : RED) : 1024;
     __shared__ float lds[LDSN];
     float* Xs = lds; float* Ds = lds + XS;
@@ -164,8 +168,9 @@ __global__ __launch_bounds__(kBlock, 3) void conv_dw16_k(const ConvBwdWArgs A) {
     for (int mt = 0; mt < MTILES; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    TileStager<CIC, 16, IH, IW, UP, KH, TH, AT, CIC, GB> st;
+    TileStager<CIC, DC, IH, IW, UP, KH, TH, AT, CIC, GB> st;
     st.init(A, ci0, co0);
+    if constexpr (DC < 16) { if (tid < 16 - DC) Ds[TH * TW * DC + tid] = 0.f; }     // the last pixel's "columns 8-15"
     auto tile_of = [&](int tl, int& b, int& y0, int& x0) {
         b = tl / A.tiles; const int tile = tl % A.tiles;
         x0 = (tile % A.tiles_x) * TW; y0 = (tile / A.tiles_x) * TH;
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(kBlock, 3) void conv_dw16_k(const ConvBwdWArgs A) {
 #pragma unroll
         for (int rs = 0; rs < 2; ++rs) {
             const int rr = wave + 4 * rs;
-            const float* dbr = Ds + (rr * TW + kk) * 16 + i;
+            const float* dbr = Ds + (rr * TW + kk) * DC + i;
             const float* xr[MTILES];
 #pragma unroll
             for (int mt = 0; mt < MTILES; ++mt) {
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(kBlock, 3) void conv_dw16_k(const ConvBwdWArgs A) {
                 else xr[mt] = Xs + aoff[mt] + (rr * IW + kk) * CIC;
             }
             auto load = [&](int ks, float (&a)[MTILES], float& bv) {
-                bv = dbr[4 * ks * 16];
+                bv = dbr[4 * ks * DC];
 #pragma unroll
                 for (int mt = 0; mt < MTILES; ++mt) a[mt] = xr[mt][(UP ? 2 * ks : 4 * ks) * CIC];
             };
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(kBlock, 3) void conv_dw16_k(const ConvBwdWArgs A) {
         if (mrow < MROWS && ci0 + ci < A.Cin && co0 + col < A.Cout)
             out[((size_t)tap * A.Cin + ci0 + ci) * A.Cout + co0 + col] = s;
     }
-    bias_reduce<16>(A, lds, bsum, out + wsize, co0, blockIdx.y == 0);
+    bias_reduce<DC>(A, lds, bsum, out + wsize, co0, blockIdx.y == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -56,7 +56,8 @@ int launch_dw_f32pipe(const ConvBwdWArgs& a, const DwPlan& p, int kh, bool up, c
     const bool gb = a.zf != nullptr;
     char nm[72];
     if (pair8) snprintf(nm, sizeof nm, "conv_dwpair8_k<%d,%s%s>", p.cic, AT_NAME(a.act_bf16), gb ? ",gb" : "");
-    else if (p.kind == 16) snprintf(nm, sizeof nm, "conv_dw16_k<%d,%d,%s,%s%s>", kh, p.cic, up ? "true" : "false", AT_NAME(a.act_bf16), gb ? ",gb" : "");
+    else if (p.kind == 16) snprintf(nm, sizeof nm, "conv_dw16_k<%d,%d,%s,%s%s%s>", kh, p.cic, up ? "true" : "false", AT_NAME(a.act_bf16), gb ? ",gb" : "",
+                                    (up && p.cic == 16 && a.Cout == 8) ? ",dz8" : "");
     else snprintf(nm, sizeof nm, "conv_dw32_k<%d,%d,%s,%d,%s%s>", kh, p.cic, up ? "true" : "false", p.th, AT_NAME(a.act_bf16), gb ? ",gb" : "");
     ProfScope ps(s, nm, c.layer, c.flops, c.bytes);
 #define GBD(...) do { if (gb) { constexpr bool GBV = true; AT_DISPATCH(a.act_bf16, __VA_ARGS__); } else { constexpr bool GBV = false; AT_DISPATCH(a.act_bf16, __VA_ARGS__); } } while (0)
@@ -65,7 +66,8 @@ int launch_dw_f32pipe(const ConvBwdWArgs& a, const DwPlan& p, int kh, bool up, c
         if (p.cic == 16) GBD(conv_dwpair8_k<16, AT, GBV><<<grid, block, 0, s>>>(a));
         else GBD(conv_dwpair8_k<8, AT, GBV><<<grid, block, 0, s>>>(a));
     } else if (p.kind == 16) {
-        if (up) { if (p.cic == 16) GBD(conv_dw16_k<2, 16, true, AT, GBV><<<grid, block, 0, s>>>(a)); else GBD(conv_dw16_k<2, 8, true, AT, GBV><<<grid, block, 0, s>>>(a)); }
+        if (up && p.cic == 16 && a.Cout == 8) GBD(conv_dw16_k<2, 16, true, AT, GBV, 8><<<grid, block, 0, s>>>(a));     // dz staged 8 wide
+        else if (up) { if (p.cic == 16) GBD(conv_dw16_k<2, 16, true, AT, GBV><<<grid, block, 0, s>>>(a)); else GBD(conv_dw16_k<2, 8, true, AT, GBV><<<grid, block, 0, s>>>(a)); }
         else { if (p.cic == 16) GBD(conv_dw16_k<3, 16, false, AT, GBV><<<grid, block, 0, s>>>(a)); else GBD(conv_dw16_k<3, 8, false, AT, GBV><<<grid, block, 0, s>>>(a)); }
     } else if (p.kind == 32) {
         if (up) { if (p.cic == 64) GBD(conv_dw32_k<2, 64, true, 2, AT, GBV><<<grid, block, 0, s>>>(a)); else GBD(conv_dw32_k<2, 32, true, 4, AT, GBV><<<grid, block, 0, s>>>(a)); }

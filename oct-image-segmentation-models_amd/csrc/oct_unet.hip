@@ -210,7 +210,8 @@ DwPlan dw_plan(const Layer& l, int B, int mfma_mode, int bf16, const Options& o)
     const int total = B * p.tiles;
     // one full round of resident blocks (no half-empty tail round): the wide kernel fits 2 blocks per CU (registers),
     // for the thin one 768 blocks measured best
-    const int target = p.kind == 32 ? o.dw32_blocks : o.dw16_blocks;
+    int target = p.kind == 32 ? o.dw32_blocks : o.dw16_blocks;
+    if (p.kind == 16 && l.src == SRC_UP && p.cic == 16 && l.cout == 8) target = target * 4 / 3;   // (dz staged 8 wide: 4 blocks per CU)
     p.npb = std::max(1, std::min(total, cdiv(target, p.chunks)));
     return p;
 }
