@@ -194,6 +194,9 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   can (the bf16-pipe conv kernels; every MFMA backward-weights kernel); the bn_bwd_apply pass (3 tensor passes per
  *   block) disappears.  Same two fmas per element as the stand-alone pass: bit-identical gradients.  The block's g buffer
  *   then keeps g' (oct_unet_debug_layer_fused tells which blocks).  0 = separate pass everywhere.
+ *   "fuse_bn_apply16" (1): ... including the thin backward-data launches with 16 K and 16 output channels (their transform
+ *   coefficients live in LDS: the registers are taken by two raw tiles, the mask input and the weights); 0 = those blocks
+ *   keep the separate pass (same step time at B = 32, 256x512; 0.2 GB more HBM traffic per step).
  *   "fuse_bn_finalize" (0): 1 = the BN records of the thin layers (<= 32 channels) are written by the LAST block of the
  *   launch that produces the partial rows (arrival counter; write-through rows; csrc/kernels_fin.hpp) instead of by a
  *   bn_*_finalize launch.  Same results to fp32 rounding; measured 0.5-1 % slower per step than the launches it removes,

@@ -32,6 +32,7 @@ struct Options {
     int bx_waves = 8;               // waves per block of conv_bx_k where the tile has >= 8 rows
     int fuse_first_apply = 1;       // the first conv's BN-backward transform is applied inside its backward-weights kernel
     int fuse_bn_apply = 1;          // every other block: the transform is applied by the dX / dW kernels while they stage g'
+    int fuse_bn_apply16 = 1;        // ... also for the 16-K / 16-output thin backward-data launches (coefficients kept in LDS there)
     int fuse_dw_thin = 1;           // 3x3 layers with 8 output channels: backward-weights reduced inside the backward-data launches
     int timing_skip = 0;            // TIMING EXPERIMENTS ONLY (results become wrong): bit 0 / 1 = skip the forward / backward BN finalize launches after step 2
     int fuse_bn_finalize = 0;       // 1: the BN records of the thin layers are written by the last block of the launch that emits the

@@ -995,10 +995,15 @@ __global__ __launch_bounds__(kBlock, FDW ? 2 : (CT == 32 ? 1 : (CT == 16 ? 2 : 3
         } else return P * PIXB + ((o ^ ((P >> SWS) & (OCT - 1))) * 16);
     };
     constexpr int XPL = TH * TW * 16, XIMG_B = FDW ? NS * XPL : 0;      // FDW: the tile's own X pixels, [term][pixel][8 ch]
-    __shared__ __attribute__((aligned(256))) char smem[2 * IN_B + 2 * XIMG_B + (4 * MB + 4 * 2 * MB) * 4];
+    // GBL: the 16-K / 16-output mask launch with fp32 activations holds two raw register sets (g' and z), the mask z and 60
+    // weight registers -- the 24 transform coefficients no longer fit under the 256-register budget of two blocks per CU
+    // (21 spills); they live in LDS and are re-read by every staging item (6 ds_read_b128, hidden among the MFMAs)
+    constexpr bool GBL = GB && CT == 16 && EPI == EPI_MASK && !FDW && sizeof(AT) == 4;
+    __shared__ __attribute__((aligned(256))) char smem[2 * IN_B + 2 * XIMG_B + (4 * MB + 4 * 2 * MB) * 4 + (GBL ? 3 * CT * 4 : 0)];
     char* const Xs = smem + 2 * IN_B;
     float* const epi = reinterpret_cast<float*>(smem + 2 * IN_B + 2 * XIMG_B);     // EPI_MASK: producer's BN rows a / b / mean / rstd
     float* const red = epi + 4 * MB;
+    float* const gbs = red + 4 * 2 * MB;                                           // GBL: rows ga, gb, gd of the K channels
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, kg = lane >> 4;
@@ -1039,7 +1044,13 @@ __global__ __launch_bounds__(kBlock, FDW ? 2 : (CT == 32 ? 1 : (CT == 16 ? 2 : 3
         for (int i = 0; i < 8; ++i) { fa[i] = ab[ccx + i]; fb[i] = ab[Cs + ccx + i]; }
     }
     float fz[GB ? 8 : 1];
-    if constexpr (GB) load_gb8(A.gb_bn, A.Cin, c8, fa, fz, fb);     // fa = ga, fz = gb, fb = gd (one source: no concat)
+    if constexpr (GBL) {
+        if (tid < 3 * CT) {
+            const int row = tid / CT, c = tid % CT;
+            gbs[tid] = c < A.Cin ? A.gb_bn[(row == 0 ? BN_GA : (row == 1 ? BN_GB : BN_GD)) * A.Cin + c] : 0.f;
+        }
+        __syncthreads();
+    } else if constexpr (GB) load_gb8(A.gb_bn, A.Cin, c8, fa, fz, fb);     // fa = ga, fz = gb, fb = gd (one source: no concat)
     // z of the layer sits at the same element offsets as g' (both are carved from the handle's workspace)
     const ptrdiff_t zdelta = GB ? reinterpret_cast<const AT*>(A.gb_z) - reinterpret_cast<const AT*>(A.x0) : 0;
     int sly[NSLOT], slx[NSLOT], sdst[NSLOT];
@@ -1100,7 +1111,13 @@ __global__ __launch_bounds__(kBlock, FDW ? 2 : (CT == 32 ? 1 : (CT == 16 ? 2 : 3
         if constexpr (GB) {
             const float4 z0 = widen4(RS.z[k][0]), z1 = widen4(RS.z[k][1]);
             const float zv[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
-            gb8<AT>(v, zv, fa, fz, fb, in);
+            if constexpr (GBL) {
+                const float4 a0 = ld4(gbs + c8), a1 = ld4(gbs + c8 + 4), b0 = ld4(gbs + CT + c8), b1 = ld4(gbs + CT + c8 + 4);
+                const float4 d0 = ld4(gbs + 2 * CT + c8), d1 = ld4(gbs + 2 * CT + c8 + 4);
+                const float la[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, lb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                const float ld[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                gb8<AT>(v, zv, la, lb, ld, in);
+            } else gb8<AT>(v, zv, fa, fz, fb, in);
             if constexpr (FDW) {      // bias gradient = column sums of dz over the tile's OWN pixels (the halo belongs to neighbours)
                 const bool own = stage_live && sly[k] >= 1 && sly[k] <= TH && slx[k] >= 1 && slx[k] <= TW;
 #pragma unroll

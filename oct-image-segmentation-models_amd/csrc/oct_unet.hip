@@ -771,7 +771,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             //  channels with 16 output channels, where the second raw register set spills under the 256-register budget of two
             //  blocks per CU: 87 us against 45 + 33 for the separate pass at B = 32, 128 x 256)
             fuse = o.fuse_bn_apply && dwkind != 0 && r0 != ROUTE_F32 && !(up && r0 == ROUTE_BX && l.cout > kBxGbDown2MaxC) &&
-                   !(r0 == ROUTE_BT && l.cout == 32) && !(r0 == ROUTE_BT && l.cout == 16 && cg == 16) &&
+                   !(r0 == ROUTE_BT && l.cout == 32) && !(r0 == ROUTE_BT && l.cout == 16 && cg == 16 && !o.fuse_bn_apply16) &&
                    (l.src != SRC_CONCAT || conv_route(dx_args(nullptr, cg, cg, nullptr, false), A_NORMAL, o) != ROUTE_F32);
         }
         l.g_masked = fuse;
@@ -1267,7 +1267,7 @@ const Opt k_opts[] = {
     {"dw_side_stream", &Options::dw_side_stream, 0, 1}, {"timing_skip", &Options::timing_skip, 0, 255}, {"fuse_dw_thin", &Options::fuse_dw_thin, 0, 1},
     {"dwbx_enable", &Options::dwbx_enable, 0, 1},
     {"bx_two_blocks", &Options::bx_two_blocks, 0, 1}, {"fork_on_launch", &Options::fork_on_launch, 0, 1},
-    {"event_sysfence", &Options::event_sysfence, 0, 1}, {"dw_fork_group", &Options::dw_fork_group, 1, 8},
+    {"event_sysfence", &Options::event_sysfence, 0, 1}, {"dw_fork_group", &Options::dw_fork_group, 1, 8}, {"fuse_bn_apply16", &Options::fuse_bn_apply16, 0, 1},
 };
 }  // namespace
 
