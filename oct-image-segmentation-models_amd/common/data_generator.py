@@ -124,7 +124,8 @@ class BatchGenerator:
                 lab = np.argmax(lab, axis=-1)
             elif lab.ndim == 4:
                 lab = lab[..., 0]
-            self._sparse_cache = np.ascontiguousarray(lab.astype(np.uint8))
+            # (no copy for the usual (N,H,W,1) uint8 array: a view -- the copy was 1 GB per 8192 scans, inside the first epoch)
+            self._sparse_cache = np.ascontiguousarray(lab, dtype=np.uint8)
         return self._sparse_cache
 
     def next_batch_u8(self):

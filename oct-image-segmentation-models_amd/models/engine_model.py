@@ -252,15 +252,20 @@ class Model:
 
     def _upload(self, X: np.ndarray, lab: np.ndarray, slot: int):
         """Queue the upload of one batch into device slot ``slot`` on the COPY stream (never on the compute stream: 8 MB of
-        uint8 per 32-scan batch would otherwise sit in front of every step).  Pinned staging buffers and device buffers are
-        double buffered: slot s is refilled only after (host) the copy that last read its pinned buffers has run and
-        (device) the step that last read its device tensors has finished.  Returns (x, labels, ready event)."""
+        uint8 per 32-scan batch would otherwise sit in front of every step).  Pinned staging buffers and device buffers come
+        in THREE slots: slot s is refilled only after the step that last read its device tensors has finished -- a HOST
+        wait on that step's event, two steps back, which also keeps this thread at most two steps ahead of the GPU.  (With two
+        slots the copy had to wait for the previous step on the copy stream; the H2D call then held the host until that
+        step was over and every step started with the launch latency exposed: 0.91 of the resident-input rate.)
+        Returns (x, labels, ready event)."""
         dev = self._engine.device if self._engine is not None else self._dev()
         st = self.__dict__.setdefault("_up", {"copy": None, "ev": {}, "done": {}, "dev": {}})
         if dev.type != "cuda":
             return torch.from_numpy(np.ascontiguousarray(X)), torch.from_numpy(np.ascontiguousarray(lab)), None
         if st["copy"] is None:
             st["copy"] = torch.cuda.Stream(device=dev)
+        if slot in st["done"]:
+            st["done"][slot].synchronize()        # host: the step that read this slot three batches ago is over
         if slot in st["ev"]:
             st["ev"][slot].synchronize()          # host: the H2D copies that last read this slot's pinned buffers have executed
         xp, lp = self._staged(("x", slot), X), self._staged(("l", slot), lab)
@@ -268,8 +273,6 @@ class Model:
         if bufs is None or bufs[0].shape != xp.shape or bufs[0].dtype != xp.dtype or bufs[1].shape != lp.shape:
             bufs = st["dev"][slot] = (torch.empty(xp.shape, dtype=xp.dtype, device=dev), torch.empty(lp.shape, dtype=lp.dtype, device=dev))
         with torch.cuda.stream(st["copy"]):
-            if slot in st["done"]:
-                st["copy"].wait_event(st["done"][slot])     # device: the step that read this slot two batches ago is over
             bufs[0].copy_(xp, non_blocking=True); bufs[1].copy_(lp, non_blocking=True)
             ev = torch.cuda.Event(); ev.record(st["copy"])
         st["ev"][slot] = ev
@@ -307,7 +310,7 @@ class Model:
             if ready is not None:
                 torch.cuda.current_stream(x.device).wait_event(ready)
             if i + 1 < n:
-                nxt = self._upload(*self._host_batch(seq, i + 1, rank, world), (i + 1) & 1)
+                nxt = self._upload(*self._host_batch(seq, i + 1, rank, world), (i + 1) % 3)
             eng = self._ensure_engine(x.shape[0], training)
             if focal:      # (re)selected per batch: _ensure_engine may have built a new engine
                 eng.set_focal_dice(focal["focal_loss_weight"], focal["gamma"], focal["class_weight"])
@@ -323,7 +326,7 @@ class Model:
                 red.backward_and_reduce(lab, macro=macro, loss_scale=1.0 / world)
                 self.optimizer.apply(eng)
             acc = loss4.clone() if acc is None else acc + loss4
-            self._release(i & 1)
+            self._release(i % 3)
         if acc is None:
             return {}
         acc = acc / n
