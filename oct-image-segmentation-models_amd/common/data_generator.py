@@ -128,11 +128,15 @@ class BatchGenerator:
             self._sparse_cache = np.ascontiguousarray(lab, dtype=np.uint8)
         return self._sparse_cache
 
-    def next_batch_u8(self):
+    def next_batch_u8(self, shard: Optional[Tuple[int, int]] = None):
+        """The next GLOBAL batch; with ``shard = (lo, hi)`` only samples lo..hi-1 of it are gathered (a DP rank's slice:
+        every rank advances the same shuffled order, none of them assembles the other ranks' scans)."""
         if self.images_u8.dtype != np.uint8:
             raise TypeError(f"next_batch_u8 needs a uint8 image array, the dataset holds {self.images_u8.dtype}; "
                             "use get_batch_list() (float32(images) / 255)")
         idx = self._next_indices()
+        if shard is not None:
+            idx = idx[shard[0]:shard[1]]
         return self.images_u8[idx], self.sparse_labels()[idx]
 
     def handle_epoch_end(self):
@@ -164,8 +168,12 @@ class DataGenerator:
         X, y = self.batch_gen.get_batch_list()
         return X, y
 
-    def next_batch_u8(self):
-        return self.batch_gen.next_batch_u8()
+    def next_batch_u8(self, shard: Optional[Tuple[int, int]] = None):
+        return self.batch_gen.next_batch_u8(shard)
+
+    @property
+    def batch_size(self) -> int:
+        return self.batch_gen.batch_size
 
     def on_epoch_end(self):
         self.batch_gen.handle_epoch_end()

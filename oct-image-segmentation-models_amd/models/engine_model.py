@@ -241,6 +241,8 @@ class Model:
     def _host_batch(self, seq, index, rank, world):
         """One GLOBAL batch from the Sequence -> this rank's (x, sparse uint8 labels) host arrays."""
         if getattr(seq, "oct_fast_path", False):
+            if world > 1:      # gather this rank's slice only (8 ranks: 1/8 of the host work per step and rank)
+                return seq.next_batch_u8(parallel.shard_batch(seq.batch_size, rank, world))
             X, lab = seq.next_batch_u8()
         else:
             X, y = seq[index]

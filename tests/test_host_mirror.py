@@ -83,6 +83,15 @@ def test_data_generator_contract():
     order1 = g.batch_gen.sample_shuffle
     assert sorted(order1) == list(range(10)) and not np.array_equal(order0, order1)
     assert g.batch_gen.full_counter == 0
+    # a DP rank's slice of the global batch: only those samples are gathered, the shuffled order advances by a whole batch
+    xs, ls = g.next_batch_u8((2, 4))
+    assert g.batch_size == 4 and xs.shape[0] == 2 and np.array_equal(xs, images[order1[2:4]]) and np.array_equal(ls, labels[order1[2:4], ..., 0])
+    xn, _ = g.next_batch_u8((0, 2))
+    assert np.array_equal(xn, images[order1[4:6]])
+    # the sparse-label cache of a (N,H,W,1) uint8 array is a view, not a copy
+    assert np.shares_memory(g.batch_gen.sparse_labels(), labels) is False      # (one-hot labels here: argmax makes a new array)
+    gv = DataGenerator(images, labels, 4, [], "none", (), False, None, seed=5)
+    assert np.shares_memory(gv.batch_gen.sparse_labels(), labels)
     # wrap-around of full_counter when batches overrun the sample count
     g2 = DataGenerator(images[:5], labels[:5], 4, [], "none", (), False, None, seed=1)
     idx = [g2.batch_gen._next_indices() for _ in range(3)]

@@ -84,9 +84,9 @@ def _seed_worker(rank, world, port, tmpdir):
     taken = []
     for epoch in range(2):
         for _ in range(len(g)):
-            X, lab = g.next_batch_u8()             # the GLOBAL batch, as Model._host_batch sees it
-            lo, hi = parallel.shard_batch(X.shape[0], rank, world)
-            taken.append(X[lo:hi])
+            X, lab = g.next_batch_u8(parallel.shard_batch(g.batch_size, rank, world))   # this rank's slice of the GLOBAL
+            assert X.shape[0] == g.batch_size // world and lab.shape[0] == X.shape[0]   # batch, as Model._host_batch takes it
+            taken.append(X)
         g.on_epoch_end()
     np.savez(os.path.join(tmpdir, f"s{rank}.npz"), seed=seed, taken=np.stack(taken), stamp=stamp)
     dist.destroy_process_group()
