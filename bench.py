@@ -484,7 +484,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_inference and os.environ.get("OCT_BENCH_NO_E2E") != "1":
         try:
             from oct_image_segmentation_models_amd.evaluation import pipeline
-            out.update(pipeline.bench_fields(eng, images, C))
+            out.update(pipeline.bench_fields(eng, images, C, labels_u8=labels[..., 0]))
         except ImportError:
             pass
     if rank == 0 and world == 1 and not args.no_fit and not args.no_inference and args.act_dtype == "f32":

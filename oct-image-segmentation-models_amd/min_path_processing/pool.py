@@ -14,6 +14,7 @@ back to inline execution with a warning instead of hanging), ``get()`` of a batc
 fallback, and under ``torchrun`` the default worker count is divided by LOCAL_WORLD_SIZE."""
 from __future__ import annotations
 
+import atexit
 import logging
 import multiprocessing as mp
 import os
@@ -34,8 +35,24 @@ def _worker_init(shape_t: Tuple[int, ...], gsgrad: int) -> None:
     _graph = graph_search.create_graph_structure(shape_t, gsgrad)     # implicit grid: built once per worker
 
 
+_views = {}          # worker side: path -> read-only memmap of a batch of maps (a few most recent batches)
+
+
+def _batch_view(path: str, shape: Tuple[int, ...]) -> np.ndarray:
+    v = _views.get(path)
+    if v is None:
+        while len(_views) >= 4:
+            _views.pop(next(iter(_views)))
+        v = _views[path] = np.memmap(path, dtype=np.uint8, mode="r", shape=tuple(shape))
+    return v
+
+
 def _segment_one(task):
-    maps_hw, truths = task                                              # (C-1, H, W) uint8, (C-1, W) or None
+    if len(task) == 4:                                                  # (file of the whole batch in /dev/shm, index, shape, truths)
+        path, i, shape, truths = task
+        maps_hw = _batch_view(path, shape)[i]
+    else:
+        maps_hw, truths = task                                          # (C-1, H, W) uint8, (C-1, W) or None
     maps_t = np.ascontiguousarray(np.transpose(maps_hw, axes=[0, 2, 1]))
     pred, errors, _ = graph_search.segment_maps(maps_t, truths, _graph)
     return pred, errors
@@ -62,9 +79,32 @@ def _in_spawned_child() -> bool:
     return mp.current_process().name != "MainProcess" or mp.parent_process() is not None
 
 
+_SHM_DIR = "/dev/shm"
+_live_files = set()          # batch files not yet removed (removed when their batch is collected; all of them at exit)
+
+
+def _remove_file(path: Optional[str]) -> None:
+    if path:
+        _live_files.discard(path)
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
+def _remove_all_files() -> None:
+    for p in list(_live_files):
+        _remove_file(p)
+
+
+atexit.register(_remove_all_files)
+
+
 class SegmentPool:
     """``segment(maps, truths)``: (n, C-1, H, W) uint8 boundary maps (+ optional (n, C-1, W) truths) ->
     [(predictions uint16 (C-1, W), errors float64 (C-1, W)), ...].  ``workers <= 1`` runs inline."""
+
+    _seq = 0
 
     def __init__(self, image_shape_hw: Sequence[int], gsgrad: int = 1, workers: Optional[int] = None):
         self.shape_t = (int(image_shape_hw[1]), int(image_shape_hw[0]))   # the graph search works on the (W, H) view
@@ -93,7 +133,22 @@ class SegmentPool:
             res = [_segment_one(t) for t in tasks]
             return _Done(res)
         chunk = max(1, len(tasks) // (4 * self.workers))
-        return _Pending(self, self._pool.map_async(_segment_one, tasks, chunksize=chunk), tasks)
+        # The maps of a device batch are 33 MB at 128 x 2 x 256 x 512: pickled through the pool's pipe they cost the
+        # submitting thread 20-30 ms per batch (the thread that also drives the GPU pipeline).  Written ONCE to a file in
+        # /dev/shm (page cache: a memcpy) and mapped read-only by the workers, a task is a path and an index.
+        path = None
+        if maps.dtype == np.uint8 and maps.nbytes >= (1 << 20) and os.path.isdir(_SHM_DIR) and os.access(_SHM_DIR, os.W_OK):
+            try:
+                SegmentPool._seq += 1
+                path = os.path.join(_SHM_DIR, f"oct_gs_{os.getpid()}_{SegmentPool._seq}.u8")
+                np.ascontiguousarray(maps).tofile(path)
+                _live_files.add(path)
+            except OSError:
+                path = None
+        if path is None:
+            return _Pending(self, self._pool.map_async(_segment_one, tasks, chunksize=chunk), tasks)
+        ptasks = [(path, i, tuple(maps.shape), None if truths is None else truths[i]) for i in range(maps.shape[0])]
+        return _Pending(self, self._pool.map_async(_segment_one, ptasks, chunksize=chunk), tasks, path)
 
     def segment(self, maps: np.ndarray, truths: Optional[np.ndarray] = None) -> List[Tuple[np.ndarray, np.ndarray]]:
         return self.segment_async(maps, truths).get()
@@ -118,8 +173,8 @@ class _Done:
 class _Pending:
     """A batch in flight on the pool; ``get`` falls back to inline execution if the pool does not answer in time."""
 
-    def __init__(self, owner: SegmentPool, handle, tasks):
-        self._owner, self._h, self._tasks = owner, handle, tasks
+    def __init__(self, owner: SegmentPool, handle, tasks, path: Optional[str] = None):
+        self._owner, self._h, self._tasks, self._path = owner, handle, tasks, path
 
     def get(self, timeout: Optional[float] = None):
         try:
@@ -129,3 +184,8 @@ class _Pending:
             if _graph is None:
                 _worker_init(self._owner.shape_t, self._owner.gsgrad)
             return [_segment_one(t) for t in self._tasks]
+        finally:
+            _remove_file(self._path); self._path = None      # (workers that still map it keep their pages until they move on)
+
+    def __del__(self):
+        _remove_file(getattr(self, "_path", None))

@@ -103,6 +103,38 @@ def test_segment_pool_equals_inline_segment_maps():
     assert np.array_equal(got_async[1][0], want[1][0])
 
 
+def test_segment_pool_passes_large_batches_through_shared_memory_files():
+    """A device batch of boundary maps (>= 1 MB) reaches the workers as ONE file in /dev/shm they map read-only, not as
+    pickled arrays; same results, and the file is gone once the batch has been collected."""
+    import glob
+    import os
+    from oct_image_segmentation_models_amd.min_path_processing import graph_search, pool as gspool
+    if not (os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK)):
+        pytest.skip("/dev/shm not writable")
+    n, H, W = 6, 256, 512
+    maps = np.zeros((n, 2, H, W), np.uint8)
+    for i in range(n):
+        for c in range(2):
+            rows = (H * (c + 1) // 3 + 9 * np.sin(np.arange(W) / 31.0 + i)).astype(int)
+            maps[i, c, rows, np.arange(W)] = 255
+    assert maps.nbytes >= 1 << 20
+    grid = graph_search.create_graph_structure((W, H), 1)
+    want = [graph_search.segment_maps(np.transpose(maps[i], (0, 2, 1)), None, grid)[:2] for i in range(n)]
+    mine = os.path.join("/dev/shm", f"oct_gs_{os.getpid()}_*.u8")
+    with gspool.SegmentPool((H, W), 1, workers=2) as pool:
+        if pool.workers < 2:
+            pytest.skip("worker pool unavailable here")
+        job = pool.segment_async(maps)
+        assert len(glob.glob(mine)) == 1                      # the batch sits in one file while it is in flight
+        got = job.get()
+        assert glob.glob(mine) == []
+        again = pool.segment(maps[::-1].copy())               # a second batch: workers move on to the new file
+    for i in range(n):
+        assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][1], want[i][1], equal_nan=True)
+        assert np.array_equal(again[i][0], want[n - 1 - i][0])
+    assert glob.glob(mine) == []
+
+
 def test_pool_started_from_an_unguarded_script_falls_back_inline_instead_of_hanging(tmp_path):
     """Spawned workers re-import ``__main__``; a top-level script without the ``__main__`` guard (here: a script fed on
     stdin, which a worker cannot even open) can never bring a worker up.  The pool must notice (start-up probe with a
