@@ -6,6 +6,7 @@ set -uo pipefail
 TAG=${1:-r02}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
+rm -rf $OUT            # (gpurun merges gpurun_out/ back: without this, older runs' traces pile up beside the new ones)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py --steps 20 --warmup 5 --dump-profile $OUT/launch_table.json "$@" > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }

@@ -81,7 +81,11 @@ if pmc_steps:
 
 # ---- SQ counters: per kernel instantiation averages per launch, and what they say ----
 sq = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-for f in glob.glob(os.path.join(src, "sq_pass*", "*", "*_counter_collection.csv")):
+for d in sorted(glob.glob(os.path.join(src, "sq_pass*"))):
+    cand = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    if not cand:
+        continue
+    f = max(cand, key=os.path.getmtime)          # newest run of this pass only (older runs may still lie in the directory)
     for r in csv.DictReader(open(f)):
         if "oct::" not in r["Kernel_Name"]:
             continue

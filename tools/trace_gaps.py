@@ -15,9 +15,10 @@ def short(n):
 def main():
     d = sys.argv[1]
     files = glob.glob(d + '/**/*_kernel_trace.csv', recursive=True)
-    rows = []
-    for f in files:
-        rows += list(csv.DictReader(open(f)))
+    if not files:
+        print('no *_kernel_trace.csv under', d); return
+    import os
+    rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))      # newest run only
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     idx = [i for i, r in enumerate(rows) if 'adam_k' in r['Kernel_Name']]
     if len(idx) < 3:
