@@ -91,15 +91,18 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_k(const PoolBwdArgs A) {
 // 4*C-byte pixel -- 1.25 TB/s at C = 64).  Needs C/4 a power of two <= 64: a thread's quad is then the same in every
 // grid-stride iteration, its statistics stay in registers, and lanes with equal quad are summed by xor-shuffles.
 // grid (nblk); one statistics row per block.
-template <typename AT>
+// V = channels per thread (4, or 8 for bf16 storage: 16-byte accesses there too -- with 4 a lane moves 8 bytes per access and
+// the kernel reaches 2.5 TB/s on the 537 MB tensors of configs[2] where the fp32 form reaches 4.4).
+template <typename AT, int V = 4>
 __global__ __launch_bounds__(kBlock) void pool_bwd_flat_k(const PoolBwdArgs A, int B) {
-    __shared__ float sh[4][64][8];
-    const int C4 = A.C >> 2, Ho = A.H >> 1, Wo = A.W >> 1;
-    const size_t n = (size_t)B * Ho * Wo * C4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = 4 * (tid % C4);
-    float a[4], bb[4], mean[4], rstd[4], s1[4], s2[4];
+    static_assert(V == 4 || V == 8, "channels per thread");
+    __shared__ float sh[4 * 64 * 8];                       // [wave][channel group][2 V]
+    const int CV = A.C / V, Ho = A.H >> 1, Wo = A.W >> 1;
+    const size_t n = (size_t)B * Ho * Wo * CV;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = V * (tid % CV);
+    float a[V], bb[V], mean[V], rstd[V], s1[V], s2[V];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < V; ++k) {
         a[k] = A.bn[BN_A * A.C + c + k]; bb[k] = A.bn[BN_B * A.C + c + k];
         mean[k] = A.bn[BN_MEAN * A.C + c + k]; rstd[k] = A.bn[BN_RSTD * A.C + c + k];
         s1[k] = 0.f; s2[k] = 0.f;
@@ -107,21 +110,29 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_flat_k(const PoolBwdArgs A, i
     const AT* Az = reinterpret_cast<const AT*>(A.z); AT* Ag = reinterpret_cast<AT*>(A.g);
     const AT* Agp = reinterpret_cast<const AT*>(A.gp);
     for (size_t i = (size_t)blockIdx.x * kBlock + tid; i < n; i += (size_t)gridDim.x * kBlock) {
-        size_t r = i / C4;
+        size_t r = i / CV;
         const int xo = (int)(r % Wo); r /= Wo;
         const int yo = (int)(r % Ho); const int b = (int)(r / Ho);
-        const float4 gq = lda4<AT>(Agp + (((size_t)b * Ho + yo) * Wo + xo) * A.C + c);
-        const float gpv[4] = {gq.x, gq.y, gq.z, gq.w};
-        size_t off[4]; float zv[4][4], gd[4][4];
+        float gpv[V];
+        size_t off[4]; float zv[4][V], gd[4][V];
+        const size_t goff = (((size_t)b * Ho + yo) * Wo + xo) * A.C + c;
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+            const float4 gq = lda4<AT>(Agp + goff + j);
+            gpv[j] = gq.x; gpv[j + 1] = gq.y; gpv[j + 2] = gq.z; gpv[j + 3] = gq.w;
+        }
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             off[w] = (((size_t)b * A.H + 2 * yo + (w >> 1)) * A.W + 2 * xo + (w & 1)) * A.C + c;
-            const float4 t = lda4<AT>(Az + off[w]), u = lda4<AT>(Ag + off[w]);
-            zv[w][0] = t.x; zv[w][1] = t.y; zv[w][2] = t.z; zv[w][3] = t.w;
-            gd[w][0] = u.x; gd[w][1] = u.y; gd[w][2] = u.z; gd[w][3] = u.w;
+#pragma unroll
+            for (int j = 0; j < V; j += 4) {
+                const float4 t = lda4<AT>(Az + off[w] + j), u = lda4<AT>(Ag + off[w] + j);
+                zv[w][j] = t.x; zv[w][j + 1] = t.y; zv[w][j + 2] = t.z; zv[w][j + 3] = t.w;
+                gd[w][j] = u.x; gd[w][j + 1] = u.y; gd[w][j + 2] = u.z; gd[w][j + 3] = u.w;
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V; ++k) {
             float yv[4]; int am = 0; float best = -1.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -136,21 +147,24 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_flat_k(const PoolBwdArgs A, i
             }
         }
 #pragma unroll
-        for (int w = 0; w < 4; ++w) sta4<AT>(Ag + off[w], make_float4(gd[w][0], gd[w][1], gd[w][2], gd[w][3]));
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int j = 0; j < V; j += 4) sta4<AT>(Ag + off[w] + j, make_float4(gd[w][j], gd[w][j + 1], gd[w][j + 2], gd[w][j + 3]));
     }
-    for (int o = C4; o < 64; o <<= 1)
+    for (int o = CV; o < 64; o <<= 1)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s1[k] += __shfl_xor(s1[k], o, 64); s2[k] += __shfl_xor(s2[k], o, 64); }
-    if (lane < C4) {
+        for (int k = 0; k < V; ++k) { s1[k] += __shfl_xor(s1[k], o, 64); s2[k] += __shfl_xor(s2[k], o, 64); }
+    if (lane < CV) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { sh[wave][lane][k] = s1[k]; sh[wave][lane][4 + k] = s2[k]; }
+        for (int k = 0; k < V; ++k) { sh[(wave * CV + lane) * 2 * V + k] = s1[k]; sh[(wave * CV + lane) * 2 * V + V + k] = s2[k]; }
     }
     __syncthreads();
     if (tid < A.C) {
-        const int qq = tid >> 2, k = tid & 3;
+        const int qq = tid / V, k = tid % V;
         float* out = A.part + (size_t)blockIdx.x * (2 * A.C);
-        part_store(out + tid, (sh[0][qq][k] + sh[1][qq][k]) + (sh[2][qq][k] + sh[3][qq][k]));           // fixed order
-        part_store(out + A.C + tid, (sh[0][qq][4 + k] + sh[1][qq][4 + k]) + (sh[2][qq][4 + k] + sh[3][qq][4 + k]));
+        auto at = [&](int w, int j) { return sh[(w * CV + qq) * 2 * V + j]; };
+        part_store(out + tid, (at(0, k) + at(1, k)) + (at(2, k) + at(3, k)));           // fixed order
+        part_store(out + A.C + tid, (at(0, V + k) + at(1, V + k)) + (at(2, V + k) + at(3, V + k)));
     }
     if (A.fin.counter) finalize_in_launch(A.fin, A.part, gridDim.x, A.C, gridDim.x, reinterpret_cast<char*>(sh));
 }

@@ -863,12 +863,14 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
                 const int bf = h->cfg.dtype, c4 = p.cout / 4;
                 const double pbytes = (double)B * p.H * p.W * p.cout * (bf ? 2 : 4) * 3.25;
                 if (c4 >= 1 && c4 <= 64 && (c4 & (c4 - 1)) == 0) {     // flat, channel-contiguous mapping
-                    const size_t items = (size_t)B * (p.H / 2) * (p.W / 2) * c4;
+                    const bool v8 = bf && p.cout % 8 == 0;                               // bf16 storage: 8 channels (16 bytes) per thread
+                    const size_t items = (size_t)B * (p.H / 2) * (p.W / 2) * (v8 ? c4 / 2 : c4);
                     const size_t cap = (size_t)B * cdiv(p.H, 2) * cdiv(p.W, kTileX);     // statistic rows carve() guarantees
                     const int grid = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(cdiv((int)items, kBlock), 2048), cap));
                     if (fin_ok(h, p)) { pb.fin = fin_desc(h, li - 1, 1, B); pending_fin = true; }
-                    ProfScope ps(s, bf ? "pool_bwd_flat_k<unsigned short>" : "pool_bwd_flat_k<float>", p.name, 0, pbytes);
-                    AT_DISPATCH(bf, pool_bwd_flat_k<AT><<<grid, kBlock, 0, s>>>(pb, B));
+                    ProfScope ps(s, bf ? (v8 ? "pool_bwd_flat_k<unsigned short,8>" : "pool_bwd_flat_k<unsigned short>") : "pool_bwd_flat_k<float>", p.name, 0, pbytes);
+                    if (v8) pool_bwd_flat_k<bf16_t, 8><<<grid, kBlock, 0, s>>>(pb, B);
+                    else AT_DISPATCH(bf, pool_bwd_flat_k<AT><<<grid, kBlock, 0, s>>>(pb, B));
                     HIP_OK(hipGetLastError());
                     pending_nblk = grid;
                     break;
