@@ -120,8 +120,9 @@ int oct_unet_backward(oct_unet* h, const unsigned char* labels_dev, int macro, f
 /* ---- data-parallel overlap (reference: tf.distribute.MirroredStrategy, training/training.py:185-188,243) ----
  * The gradient buffer has the parameter layout (Keras creation order: encoder, bottleneck, decoder, head) and backward
  * runs head -> decoder -> bottleneck -> encoder.  With a tail event set, oct_unet_backward sums the partial slabs of
- * every layer from the first bottleneck conv on as soon as that conv's gradients are queued and records the event on
- * `stream`: floats [oct_unet_grad_tail_offset(cfg), param_count) of grads are final from then on, so the launcher can
+ * every layer from the first bottleneck conv on as soon as that conv's gradients are queued and records the event behind
+ * that sum (on the handle's internal side stream when "dw_side_stream" is on -- `stream` does not wait for it -- else on
+ * `stream`): floats [oct_unet_grad_tail_offset(cfg), param_count) of grads are final from then on, so the launcher can
  * all-reduce that TAIL segment (bottleneck + decoder + head: 97 % of the floats) on a side stream (after
  * hipStreamWaitEvent) while the encoder backward still runs, and the remaining ENCODER segment [0, offset) after
  * backward.  hip_event: a hipEvent_t owned by the caller, NULL disables.  If oct_unet_backward returns an error the

@@ -790,7 +790,7 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
         // side stream waits for costs the caller's stream ~6 us in front of its next launch (the dispatch that carries the
         // completion signal has to be retired by the command processor first), and a block's dz, z and record stay valid
         // until the end of the backward pass, so its backward-weights kernel may start a block or two late.
-        const bool tail_here = h->tail_event && li == first_mid_layer(pl);
+        const bool tail_here = li == first_mid_layer(pl);      // every gradient from the first bottleneck conv on is queued here
         if (fork) pend.push_back({li, fuse});
         const bool flush = !pend.empty() && (!fork || (int)pend.size() >= o.dw_fork_group || tail_here);
         hipEvent_t fe = flush ? h->fork_ev[1 + n_forks++ % (h->fork_ev.size() - 1)] : nullptr;
@@ -812,14 +812,17 @@ int backward_impl(oct_unet* h, const void* x_in, int x_is_u8, const unsigned cha
             rc = conv_backward_w(h, li, x_in, x_is_u8, l.g, B, s, fuse);
             if (rc) return rc;
         }
-        if (tail_here) {
-            if (forked) { HIP_OK(hipEventRecord(h->join_ev, h->side)); HIP_OK(hipStreamWaitEvent(s, h->join_ev, 0)); }
+        if (tail_here && (forked || h->tail_event)) {
             // every parameter gradient at offsets >= L[li].w_off (bottleneck, decoder, head: Keras creation order) is
             // final once the queued slabs are summed: the DP launcher all-reduces that segment on a side stream while
-            // the encoder backward runs
-            rc = flush_reduce(h, s);
+            // the encoder backward runs.  The sum runs on the handle's side stream, behind the backward-weights
+            // kernels that write those slabs (the slabs written by launches of the caller's stream -- head, fused dX+dW --
+            // are older than the fork event that stream last waited for): the caller's stream neither waits for the side
+            // stream here nor carries the reduce, and the end-of-backward reduce is left with the encoder's slabs.
+            hipStream_t rs = forked ? h->side : s;
+            rc = flush_reduce(h, rs);
             if (rc) return rc;
-            HIP_OK(hipEventRecord(h->tail_event, s));
+            if (h->tail_event) HIP_OK(hipEventRecord(h->tail_event, rs));
         }
         if (l.src == SRC_INPUT) break;
         if (prep_pending) { HIP_OK(hipStreamWaitEvent(s, h->prep_ev, 0)); prep_pending = false; }   // first backward-data launch
