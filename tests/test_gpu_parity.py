@@ -58,7 +58,7 @@ DROP_STEP = 3
 
 @pytest.fixture(params=["tile_per_block", "persistent", "thin8_valu", "pair8_mfma", "pair8_mfma_111", "dw16_padded",
                         "bx_tall", "bx_tall_w4", "f32_pipe", "dwbt_all", "bt_one_px", "bn_apply_separate",
-                        "bn_finalize_in_launch", "bx_one_block", "dw_thin_separate", "bn_apply16_separate", "fork_marker_grouped"])
+                        "bn_finalize_in_launch", "bx_one_block", "dw_thin_separate", "bn_apply16_separate", "fork_marker_grouped", "no_side_stream"])
 def variant(request):
     """Run the same verified inputs through every conv kernel variant: for the thin layers the persistent
     software-pipelined, VALU and pixel-pair MFMA kernels (otherwise only chosen on large grids); for the wide layers the
@@ -82,6 +82,7 @@ def variant(request):
     _hip.set_option("fork_on_launch", 0 if v == "fork_marker_grouped" else 1)
     _hip.set_option("event_sysfence", 1 if v == "fork_marker_grouped" else 0)
     _hip.set_option("dw_fork_group", 3 if v == "fork_marker_grouped" else 1)
+    _hip.set_option("dw_side_stream", 0 if v == "no_side_stream" else 1)       # everything on the caller's stream
     _hip.set_option("igemm_persistent_min_tiles", 1 if v == "persistent" else 1 << 30)
     _hip.set_option("thin8_min_tiles", 1 if v == "thin8_valu" or v.startswith("pair8") else 1 << 30)
     _hip.set_option("pair8_min_tiles", 1 if v.startswith("pair8") else 1 << 30)
@@ -102,6 +103,7 @@ def variant(request):
     _hip.set_option("fork_on_launch", 1)
     _hip.set_option("event_sysfence", 0)
     _hip.set_option("dw_fork_group", 1)
+    _hip.set_option("dw_side_stream", 1)
     _hip.set_option("dwpair8_enable", 1)
     _hip.set_option("igemm_persistent_min_tiles", 2048)
     _hip.set_option("thin8_min_tiles", 2048)
