@@ -209,6 +209,9 @@ int oct_boundary_maps(const unsigned char* labels_dev, int B, int H, int W, int 
  *   launch itself (hipExtLaunchKernelGGL stopEvent) rather than a marker recorded behind it.  "dw_fork_group" (1): blocks
  *   whose backward-weights launches share one fork (2-4: fewer waits on the caller's stream, measured slower overall).
  *   "event_sysfence" (0; read at oct_unet_create): 1 = the handle's internal fork/join events carry a system-scope fence.
+ *   Experiment switches, not for production use: "dwbx_enable" (1; 0 routes the wide backward-weights layers to the
+ *   fp32-pipe kernel) and "timing_skip" (0; bit 0 / 1 SKIP the forward / backward BN finalize launches after the second
+ *   step -- the results are then WRONG; used once to measure what those launches cost).
  *   "igemm_persistent_min_tiles" (default 2048): number of pixel tiles from which thin single-chunk convs use the
  *   persistent software-pipelined kernel instead of the one-tile-per-block kernel.
  *   "thin8_min_tiles" (default 2048): number of pixel tiles from which 8-output-channel convs run on the VALU
